@@ -1,0 +1,195 @@
+/*
+ * lnrf.h — C ABI of the MI355X-native NeRF volume-rendering hot path (liblnrf.so).
+ *
+ * The reference (unixpickle/learn-nerf) has no FFI: its hot path is Python on JAX
+ * (SURVEY.md §8b).  This header is the boundary a maintainer binds instead of
+ * jax.jit: every entry point names the reference function (file:line under
+ * /root/reference/learn_nerf) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in signatures
+ *     (lnrf_stream_t is a hipStream_t passed as void*; NULL = default stream).
+ *   - every pointer is DEVICE memory unless marked (host); the caller owns every
+ *     buffer, the library allocates nothing persistent.
+ *   - all work is enqueued asynchronously on the given stream; no hidden sync.
+ *   - return 0 = ok, <0 = lnrf argument/shape error, >0 = hipError_t passthrough;
+ *     message via lnrf_last_error() (thread-local).  Never throws or aborts.
+ *   - arrays are row-major contiguous fp32 unless noted; rays are
+ *     (origin[3], direction[3]) with `ray_stride` floats between consecutive rays
+ *     (6 for [N,2,3] batches, 9 for [N,3,3] training batches with colours).
+ *   - sampling noise: `u` (explicit uniforms in [0,1)) or, when u == NULL, the
+ *     Philox4x32-10 stream (seed, stream_id, element (ray_offset+n)*count+i)
+ *     documented in oracle/philox.py.
+ */
+#ifndef LNRF_H
+#define LNRF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lnrf_stream_t;
+
+#define LNRF_VERSION 100 /* 0.1.0 */
+
+#define LNRF_OK 0
+#define LNRF_ERR_ARG (-1)
+#define LNRF_ERR_SHAPE (-2)
+#define LNRF_ERR_UNSUPPORTED (-3)
+
+/* activation codes for the dense kernels */
+#define LNRF_ACT_NONE 0
+#define LNRF_ACT_RELU 1
+#define LNRF_ACT_SOFTPLUS 2
+#define LNRF_ACT_TANH 3
+#define LNRF_ACT_EXP 4
+#define LNRF_ACT_SIGMOID 5
+
+int lnrf_version(void);
+const char* lnrf_last_error(void);
+
+/* ------------------------------------------------------------------ rays ---- */
+
+/* ray_t_range (render.py:346-389) + NeRFRenderer.t_range (render.py:93-111) fused with
+ * RaySamples.stratified_sampling (render.py:121-143).  bbox_min/max: (host) 3 floats.
+ * count may be 0 (then ts/u are ignored).  mask: 1 byte per ray (0/1). */
+int lnrf_ray_aabb_stratified(const float* rays, int64_t ray_stride, int64_t n_rays,
+                             const float* bbox_min, const float* bbox_max, float min_t_range,
+                             float epsilon, int32_t count, const float* u, uint64_t seed,
+                             uint32_t stream_id, int64_t ray_offset, float* t_min, float* t_max,
+                             uint8_t* mask, float* ts, lnrf_stream_t stream);
+
+/* RaySamples.stratified_sampling (render.py:121-143) from given t_min/t_max. */
+int lnrf_stratified(const float* t_min, const float* t_max, int64_t n_rays, int32_t count,
+                    const float* u, uint64_t seed, uint32_t stream_id, int64_t ray_offset,
+                    float* ts, lnrf_stream_t stream);
+
+/* RaySamples.points (render.py:145-153) + direction tile (render.py:319):
+ * x[n,t,:] = o + d*ts[n,t];  dirs[n,t,:] = d.  Either output may be NULL. */
+int lnrf_ray_points(const float* rays, int64_t ray_stride, const float* ts, int64_t n_rays,
+                    int32_t t, float* points, float* dirs, lnrf_stream_t stream);
+
+/* RaySamples.fine_sampling (render.py:211-257): termination probs of the coarse pass ->
+ * inverse-CDF (jnp.interp) at stratified u' -> optional sort with the coarse ts.
+ * ts_out is [N, tc+tf] when combine != 0 else [N, tf]. */
+int lnrf_fine_sample(const float* ts_c, const float* t_min, const float* t_max,
+                     const float* density_c, int64_t n_rays, int32_t tc, int32_t tf, float eps,
+                     int32_t combine, const float* u, uint64_t seed, uint32_t stream_id,
+                     int64_t ray_offset, float* ts_out, lnrf_stream_t stream);
+
+/* RaySamples.termination_probs (render.py:270-287): probs [N, T+1]. */
+int lnrf_termination_probs(const float* ts, const float* t_min, const float* t_max,
+                           const float* density, int64_t n_rays, int32_t t, float* probs,
+                           lnrf_stream_t stream);
+
+/* RaySamples.render_rays / render_alpha / average_aux_losses and the free render_rays
+ * (render.py:155-209, 293-343) in one pass per ray:
+ *   outputs[N,3] = mask ? sum_t probs*rgb + probs_T*background : background
+ *   alphas[N]    = mask ? 1 - probs_T : 0
+ *   coords[N,3]  = mask ? sum_t probs*(o + d*ts) : 0
+ *   aux_sum[N,n_aux] = mask ? sum_t probs*aux : 0           (aux [N,T,n_aux], may be NULL)
+ * If targets != NULL (stride target_stride floats per ray), sum over rays/channels of
+ * (outputs-targets)^2 is atomically added to *sq_err (train.py:141-142 numerator).
+ * Any output pointer may be NULL. */
+int lnrf_composite_fwd(const float* rays, int64_t ray_stride, const float* ts, const float* t_min,
+                       const float* t_max, const uint8_t* mask, const float* density,
+                       const float* rgb, const float* aux, int32_t n_aux, const float* background,
+                       int64_t n_rays, int32_t t, float* outputs, float* alphas, float* coords,
+                       float* aux_sum, const float* targets, int64_t target_stride, float* sq_err,
+                       lnrf_stream_t stream);
+
+/* Backward of the compositing integral for the loss of TrainLoop.losses (train.py:140-151).
+ * Upstream gradient per ray: g_out[N,3] if non-NULL, else out_scale*(outputs - targets)
+ * (i.e. d/d outputs of mean squared error when out_scale = 2/(3*N_global)).
+ * g_aux_w: (host) n_aux weights = d total / d aux_sum[n,k] (same for every ray).
+ * Writes g_density[N,T], g_rgb[N,T,3], g_aux[N,T,n_aux]; atomically accumulates
+ * g_background[3].  No gradient flows to ts (fine sampling uses stop_gradient,
+ * render.py:76; stratified ts do not depend on parameters). */
+int lnrf_composite_bwd(const float* ts, const float* t_min, const float* t_max,
+                       const uint8_t* mask, const float* density, const float* rgb,
+                       const float* aux, int32_t n_aux, const float* background, int64_t n_rays,
+                       int32_t t, const float* g_out, const float* outputs, const float* targets,
+                       int64_t target_stride, float out_scale, const float* g_aux_w,
+                       float* g_density, float* g_rgb, float* g_aux, float* g_background,
+                       lnrf_stream_t stream);
+
+/* ----------------------------------------------------------- generic dense ---- */
+
+/* sinusoidal_emb (model.py:65-77): out[m, col_off + c*2F + {f | F+f}] = sin|cos(2^f x[m,c]).
+ * x has `dims` columns (row stride ldx), out row stride ldo. */
+int lnrf_sinusoidal_emb(const float* x, int64_t ldx, int64_t m, int32_t dims, int32_t freqs,
+                        float* out, int64_t ldo, int64_t col_off, lnrf_stream_t stream);
+
+/* flax.linen.Dense + activation (model.py:51-60): y = act(x[M,K] @ w[K,N] + b[N]).
+ * fp32 in / fp32 accumulate on the f32 MFMA.  ldx/ldy row strides (concat without copies).
+ * b may be NULL. */
+int lnrf_dense_fwd(const float* x, int64_t ldx, const float* w, const float* b, int32_t act,
+                   float* y, int64_t ldy, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
+
+/* g_pre = g_y * act'(y) elementwise in place on g (y = saved activation output). */
+int lnrf_act_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int32_t act, int64_t m,
+                 int32_t n, lnrf_stream_t stream);
+
+/* g_x[M,K] (+)= g_y[M,N] @ w[K,N]^T. accumulate != 0 adds into g_x. */
+int lnrf_dense_bwd_input(const float* gy, int64_t ldgy, const float* w, float* gx, int64_t ldgx,
+                         int32_t accumulate, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
+
+/* g_w[K,N] += x[M,K]^T @ g_y[M,N];  g_b[N] += sum_m g_y (g_b may be NULL). */
+int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gw,
+                          float* gb, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
+
+/* ------------------------------------------------ fused NeRF MLP (bf16 MFMA) ---- */
+
+/* NeRFModel hyper-parameters (model.py:35-40). The fused kernels support the reference
+ * default {5,4,256,128,10,4}; anything else returns LNRF_ERR_UNSUPPORTED (use the dense path). */
+typedef struct {
+  int32_t input_layers, mid_layers, hidden_dim, color_layer_dim, x_freqs, d_freqs;
+} lnrf_nerf_shape;
+
+/* number of fp32 parameters in Flax creation order (Dense_i.kernel[in,out], Dense_i.bias). */
+int64_t lnrf_nerf_param_count(const lnrf_nerf_shape* shape);
+/* bytes of the opaque MFMA-fragment-ordered bf16 copy produced by lnrf_nerf_pack_weights. */
+int64_t lnrf_nerf_packed_bytes(const lnrf_nerf_shape* shape);
+/* bytes of the saved-activation buffer for m evaluations (forward -> backward). */
+int64_t lnrf_nerf_save_bytes(const lnrf_nerf_shape* shape, int64_t m);
+/* bytes of backward scratch (pre-activation gradients in fragment order) for m evaluations. */
+int64_t lnrf_nerf_bwd_scratch_bytes(const lnrf_nerf_shape* shape, int64_t m);
+
+/* Repack fp32 Flax-layout parameters into the bf16 fragment streams (forward + transposed). */
+int lnrf_nerf_pack_weights(const lnrf_nerf_shape* shape, const float* params, void* packed,
+                           lnrf_stream_t stream);
+
+/* NeRFModel.__call__ (model.py:43-62) for M evaluations, positional encoding included.
+ * Points come either from explicit x[M,3], d[M,3] (rays == NULL) or, without materialising
+ * them (render.py:318-319), from rays + ts: evaluation m = n*t + i is x = o_n + d_n*ts[n,i].
+ * density[M] >= 0, rgb[M,3] in (-1,1).  save (nullable): activations for the backward. */
+int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packed, const float* x,
+                      const float* d, const float* rays, int64_t ray_stride, const float* ts,
+                      int32_t t, int64_t m, float* density, float* rgb, void* save,
+                      lnrf_stream_t stream);
+
+/* Backward of the above wrt the parameters: grads[param_count] += d L / d params given
+ * g_density[M], g_rgb[M,3] (= d L / d outputs), the forward outputs and the save buffer. */
+int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packed, const void* save,
+                      const float* density, const float* rgb, const float* g_density,
+                      const float* g_rgb, int64_t m, void* scratch, float* grads,
+                      lnrf_stream_t stream);
+
+/* ------------------------------------------------------------- optimiser ---- */
+
+/* optax.adam (train.py:59), fused over a flat buffer:
+ *   g' = g*grad_scale; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ *   p -= lr * (m/(1-b1^step)) / (sqrt(v/(1-b2^step)) + eps).   step counts from 1. */
+int lnrf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                   float b2, float eps, int32_t step, float grad_scale, lnrf_stream_t stream);
+
+/* *out += sum x^2 (tree_norm numerator, train.py:92-97). out must be zeroed by the caller. */
+int lnrf_sq_norm(const float* x, int64_t n, float* out, lnrf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LNRF_H */

@@ -1,0 +1,239 @@
+// dense.hip — generic fp32 dense layers on the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact
+// fp32 products, fp32 accumulate).  This is the model-agnostic / exact-precision path:
+// flax.linen.Dense as used at learn_nerf/model.py:51-60, instant_ngp.py:47-53, ref_nerf.py:97-107,
+// plus sinusoidal_emb (model.py:65-77).  The performance path for NeRFModel is nerf_mlp.hip.
+#include "common.h"
+
+namespace lnrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case LNRF_ACT_RELU: return fmaxf(x, 0.0f);
+    case LNRF_ACT_SOFTPLUS: return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));  // logaddexp(x, 0)
+    case LNRF_ACT_TANH: return tanhf(x);
+    case LNRF_ACT_EXP: return expf(x);
+    case LNRF_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    default: return x;
+  }
+}
+
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+  switch (act) {
+    case LNRF_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case LNRF_ACT_SOFTPLUS: return 1.0f - expf(-y);  // sigmoid(x) = 1 - exp(-softplus(x))
+    case LNRF_ACT_TANH: return 1.0f - y * y;
+    case LNRF_ACT_EXP: return y;
+    case LNRF_ACT_SIGMOID: return y * (1.0f - y);
+    default: return 1.0f;
+  }
+}
+
+constexpr int TI = 64, TJ = 64, RC = 16;
+
+// C[i][j] (op)= sum_r A(i,r) * B(r,j),  A(i,r) = a[i*sa_i + r*sa_r],  B(r,j) = b[r*sb_r + j*sb_j].
+// One workgroup = 64x64 output tile, 4 waves in a 2x2 grid of 32x32 MFMA tiles.
+// mode 0: store act(C + bias);  1: C += result (plain);  2: atomicAdd (split reduction).
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, int64_t sa_i,
+                                                       int64_t sa_r, const float* __restrict__ b,
+                                                       int64_t sb_r, int64_t sb_j,
+                                                       float* __restrict__ c, int64_t ldc,
+                                                       const float* __restrict__ bias, int act,
+                                                       int mode, int64_t I, int J, int64_t R,
+                                                       int64_t r_per_split) {
+  __shared__ float As[TI][RC + 1];
+  __shared__ float Bs[RC][TJ + 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * TI;
+  const int j0 = blockIdx.y * TJ;
+  const int64_t r_begin = (int64_t)blockIdx.z * r_per_split;
+  const int64_t r_end = r_begin + r_per_split < R ? r_begin + r_per_split : R;
+
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+
+  const bool a_r_fast = (sa_r == 1);
+  const bool b_j_fast = (sb_j == 1);
+
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += RC) {
+    // stage A tile [64][16]
+#pragma unroll
+    for (int q = 0; q < (TI * RC) / 256; ++q) {
+      const int e = q * 256 + tid;
+      int ii, rr;
+      if (a_r_fast) { rr = e % RC; ii = e / RC; } else { ii = e % TI; rr = e / TI; }
+      const int64_t gi = i0 + ii, gr = r0 + rr;
+      As[ii][rr] = (gi < I && gr < r_end) ? a[gi * sa_i + gr * sa_r] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < (RC * TJ) / 256; ++q) {
+      const int e = q * 256 + tid;
+      int jj, rr;
+      if (b_j_fast) { jj = e % TJ; rr = e / TJ; } else { rr = e % RC; jj = e / RC; }
+      const int gj = j0 + jj;
+      const int64_t gr = r0 + rr;
+      Bs[rr][jj] = (gj < J && gr < r_end) ? b[gr * sb_r + (int64_t)gj * sb_j] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < RC / 2; ++kk) {
+      const float av = As[wr * 32 + (lane & 31)][kk * 2 + (lane >> 5)];
+      const float bv = Bs[kk * 2 + (lane >> 5)][wc * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int col = j0 + wc * 32 + (lane & 31);
+  if (col < J) {
+    const float bv = (bias && mode == 0) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t row = i0 + wr * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (row < I) {
+        float* dst = c + row * ldc + col;
+        if (mode == 0) *dst = act_apply(acc[q] + bv, act);
+        else if (mode == 1) *dst += acc[q];
+        else atomicAdd(dst, acc[q]);
+      }
+    }
+  }
+}
+
+__global__ void col_sum_kernel(const float* __restrict__ g, int64_t ldg, int64_t m, int n,
+                               float* __restrict__ out) {
+  // out[j] += sum_i g[i][j]; grid.x tiles rows (1024 per block), threads stride columns
+  const int64_t rows_per_block = 1024;
+  const int64_t i0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t i1 = i0 + rows_per_block < m ? i0 + rows_per_block : m;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    float s = 0.0f;
+    for (int64_t i = i0; i < i1; ++i) s += g[i * ldg + j];
+    atomicAdd(out + j, s);
+  }
+}
+
+__global__ void act_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y,
+                               int64_t ldy, int act, int64_t m, int n) {
+  const int64_t total = m * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / n;
+    const int j = (int)(e - i * n);
+    g[i * ldg + j] *= act_grad_from_output(y[i * ldy + j], act);
+  }
+}
+
+__global__ void sinusoidal_emb_kernel(const float* __restrict__ x, int64_t ldx, int64_t m, int dims,
+                                      int freqs, float* __restrict__ out, int64_t ldo,
+                                      int64_t col_off) {
+  const int64_t total = m * dims * freqs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(e % freqs);
+    const int64_t t = e / freqs;
+    const int cdim = (int)(t % dims);
+    const int64_t row = t / dims;
+    const float arg = x[row * ldx + cdim] * (float)(1u << f);  // model.py:72-73 (2^f exact)
+    float s, c;
+    sincosf(arg, &s, &c);
+    float* o = out + row * ldo + col_off + (int64_t)cdim * 2 * freqs;
+    o[f] = s;           // model.py:74-77: per coordinate [sin block, cos block]
+    o[freqs + f] = c;
+  }
+}
+
+}  // namespace lnrf
+
+using namespace lnrf;
+
+static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r,
+                       int64_t sb_j, float* c, int64_t ldc, const float* bias, int act, int mode,
+                       int64_t I, int J, int64_t R, int splits, hipStream_t stream) {
+  if (I == 0 || J == 0) return LNRF_OK;
+  if (splits < 1) splits = 1;
+  int64_t per = (R + splits - 1) / splits;
+  per = ((per + RC - 1) / RC) * RC;
+  if (per < RC) per = RC;
+  splits = (int)((R + per - 1) / per);
+  if (splits < 1) splits = 1;
+  dim3 grid((unsigned)((I + TI - 1) / TI), (unsigned)((J + TJ - 1) / TJ), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, a, sa_i, sa_r, b, sb_r, sb_j, c, ldc,
+                     bias, act, mode, I, J, R, per);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gemm_f32");
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_dense_fwd(const float* x, int64_t ldx, const float* w, const float* b,
+                              int32_t act, float* y, int64_t ldy, int64_t m, int32_t k, int32_t n,
+                              lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(x && w && y, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes");
+  LNRF_CHECK_ARG(act >= 0 && act <= LNRF_ACT_SIGMOID, "bad activation");
+  return launch_gemm(x, ldx, 1, w, n, 1, y, ldy, b, act, 0, m, n, k, 1, as_stream(stream));
+}
+
+extern "C" int lnrf_act_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int32_t act,
+                            int64_t m, int32_t n, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(g && y, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && n >= 1 && ldg >= n && ldy >= n, "bad sizes");
+  if (m == 0 || act == LNRF_ACT_NONE) return LNRF_OK;
+  int64_t blocks = (m * n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, ldg, y,
+                     ldy, act, m, n);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_dense_bwd_input(const float* gy, int64_t ldgy, const float* w, float* gx,
+                                    int64_t ldgx, int32_t accumulate, int64_t m, int32_t k,
+                                    int32_t n, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(gy && w && gx, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && k >= 1 && n >= 1 && ldgy >= n && ldgx >= k, "bad sizes");
+  // gx[i][kk] = sum_r gy[i][r] * w[kk][r]  ->  B(r, j=kk) = w[kk*n + r]
+  return launch_gemm(gy, ldgy, 1, w, 1, n, gx, ldgx, nullptr, 0, accumulate ? 1 : 0, m, k, n, 1,
+                     as_stream(stream));
+}
+
+extern "C" int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
+                                     float* gw, float* gb, int64_t m, int32_t k, int32_t n,
+                                     lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(x && gy && gw, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldgy >= n, "bad sizes");
+  if (m == 0) return LNRF_OK;
+  // gw[kk][j] += sum_m x[m][kk] * gy[m][j]: A(i=kk, r=m) = x[m*ldx + kk]
+  const int tiles = ((k + TI - 1) / TI) * ((n + TJ - 1) / TJ);
+  int splits = (int)((2048 + tiles - 1) / tiles);
+  const int64_t max_splits = (m + 255) / 256;
+  if (splits > max_splits) splits = (int)max_splits;
+  int rc = launch_gemm(x, 1, ldx, gy, ldgy, 1, gw, n, nullptr, 0, 2, k, n, m, splits, as_stream(stream));
+  if (rc != LNRF_OK) return rc;
+  if (gb) {
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0,
+                       as_stream(stream), gy, ldgy, m, n, gb);
+    LNRF_LAUNCH_CHECK();
+  }
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_sinusoidal_emb(const float* x, int64_t ldx, int64_t m, int32_t dims,
+                                   int32_t freqs, float* out, int64_t ldo, int64_t col_off,
+                                   lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(x && out, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && dims >= 1 && freqs >= 1 && freqs <= 31 && ldx >= dims, "bad sizes");
+  LNRF_CHECK_ARG(ldo >= col_off + (int64_t)dims * 2 * freqs, "output row too short");
+  if (m == 0) return LNRF_OK;
+  int64_t blocks = (m * dims * freqs + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(sinusoidal_emb_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
+                     ldx, m, dims, freqs, out, ldo, col_off);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}

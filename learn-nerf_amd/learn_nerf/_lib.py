@@ -1,0 +1,114 @@
+"""
+ctypes binding of liblnrf.so (C ABI declared in include/lnrf.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a kernel is
+asked to run on a non-GPU tensor, this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT = os.path.normpath(os.path.join(_HERE, "..", "lib", "liblnrf.so"))
+
+ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH, ACT_EXP, ACT_SIGMOID = range(6)
+
+
+class NerfShape(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in
+                ("input_layers", "mid_layers", "hidden_dim", "color_layer_dim", "x_freqs", "d_freqs")]
+
+
+_P = c_void_p
+_F3 = POINTER(c_float)
+
+# name -> (restype, argtypes); must list every symbol of include/lnrf.h (tests check this)
+PROTOTYPES = {
+    "lnrf_version": (c_int32, []),
+    "lnrf_last_error": (c_char_p, []),
+    "lnrf_ray_aabb_stratified": (c_int32, [_P, c_int64, c_int64, _F3, _F3, c_float, c_float, c_int32, _P,
+                                           c_uint64, c_uint32, c_int64, _P, _P, _P, _P, _P]),
+    "lnrf_stratified": (c_int32, [_P, _P, c_int64, c_int32, _P, c_uint64, c_uint32, c_int64, _P, _P]),
+    "lnrf_ray_points": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
+    "lnrf_fine_sample": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P,
+                                   c_uint64, c_uint32, c_int64, _P, _P]),
+    "lnrf_termination_probs": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
+    "lnrf_composite_fwd": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32,
+                                     _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "lnrf_composite_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, _P, _P,
+                                     c_int64, c_float, _F3, _P, _P, _P, _P, _P]),
+    "lnrf_sinusoidal_emb": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P]),
+    "lnrf_dense_fwd": (c_int32, [_P, c_int64, _P, _P, c_int32, _P, c_int64, c_int64, c_int32, c_int32, _P]),
+    "lnrf_act_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int64, c_int32, _P]),
+    "lnrf_dense_bwd_input": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, c_int32, c_int32, _P]),
+    "lnrf_dense_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P]),
+    "lnrf_nerf_param_count": (c_int64, [POINTER(NerfShape)]),
+    "lnrf_nerf_packed_bytes": (c_int64, [POINTER(NerfShape)]),
+    "lnrf_nerf_save_bytes": (c_int64, [POINTER(NerfShape), c_int64]),
+    "lnrf_nerf_bwd_scratch_bytes": (c_int64, [POINTER(NerfShape), c_int64]),
+    "lnrf_nerf_pack_weights": (c_int32, [POINTER(NerfShape), _P, _P, _P]),
+    "lnrf_nerf_mlp_fwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, c_int64, _P, c_int32, c_int64, _P, _P,
+                                    _P, _P]),
+    "lnrf_nerf_mlp_bwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_adam_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
+                                 c_float, _P]),
+    "lnrf_sq_norm": (c_int32, [_P, c_int64, _P, _P]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.environ.get("LNRF_LIB", _DEFAULT)
+
+
+def lib() -> ctypes.CDLL:
+    """Load liblnrf.so once; raises if it is missing (there is no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"liblnrf.so not found at {path}: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C learn-nerf_amd/csrc`). The HIP library is required."
+            )
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().lnrf_last_error()
+        raise RuntimeError(f"lnrf error {rc} {what}: {msg.decode() if msg else ''}")
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError("lnrf kernels need tensors on a ROCm GPU device (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f3(values):
+    vals = [float(v) for v in values]
+    assert len(vals) == 3
+    return (c_float * 3)(*vals)

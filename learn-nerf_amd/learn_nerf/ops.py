@@ -1,0 +1,205 @@
+"""
+Tensor-level wrappers over the C ABI (include/lnrf.h).  Each function allocates its outputs
+with torch (device memory plumbing only) and enqueues one HIP kernel family on the current
+stream.  No arithmetic happens in Python.
+"""
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+F32 = torch.float32
+
+
+def _dev(t: torch.Tensor):
+    return t.device
+
+
+def _ray_stride(rays: torch.Tensor) -> int:
+    # [N,2,3] -> 6, [N,3,3] -> 9 (training batches keep the colour next to the ray)
+    assert rays.dim() == 3 and rays.shape[2] == 3 and rays.shape[1] in (2, 3), rays.shape
+    return rays.shape[1] * 3
+
+
+def _seed(seed) -> int:
+    return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def ray_aabb_stratified(rays, bbox_min: Sequence[float], bbox_max: Sequence[float], count: int,
+                        u: Optional[torch.Tensor] = None, seed: int = 0, stream_id: int = 0,
+                        ray_offset: int = 0, min_t_range: float = 1e-3, epsilon: float = 1e-8):
+    """ray_t_range + stratified_sampling (render.py:346-389, 121-143) -> t_min, t_max, mask, ts."""
+    n = rays.shape[0]
+    dev = _dev(rays)
+    t_min = torch.empty(n, dtype=F32, device=dev)
+    t_max = torch.empty(n, dtype=F32, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    ts = torch.empty((n, count), dtype=F32, device=dev)
+    if u is not None:
+        assert u.shape == (n, count)
+    L.check(L.lib().lnrf_ray_aabb_stratified(
+        L.ptr(rays), _ray_stride(rays), n, L.f3(bbox_min), L.f3(bbox_max), min_t_range, epsilon, count,
+        L.ptr(u), _seed(seed), stream_id, ray_offset, L.ptr(t_min), L.ptr(t_max), L.ptr(mask, torch.uint8),
+        L.ptr(ts) if count > 0 else None, L.stream()), "ray_aabb_stratified")
+    return t_min, t_max, mask, ts
+
+
+def stratified(t_min, t_max, count: int, u=None, seed: int = 0, stream_id: int = 0, ray_offset: int = 0):
+    n = t_min.shape[0]
+    ts = torch.empty((n, count), dtype=F32, device=_dev(t_min))
+    L.check(L.lib().lnrf_stratified(L.ptr(t_min), L.ptr(t_max), n, count, L.ptr(u), _seed(seed), stream_id,
+                                    ray_offset, L.ptr(ts) if count > 0 else None, L.stream()), "stratified")
+    return ts
+
+
+def ray_points(rays, ts, want_dirs: bool = True):
+    n, t = ts.shape
+    pts = torch.empty((n, t, 3), dtype=F32, device=_dev(ts))
+    dirs = torch.empty((n, t, 3), dtype=F32, device=_dev(ts)) if want_dirs else None
+    L.check(L.lib().lnrf_ray_points(L.ptr(rays), _ray_stride(rays), L.ptr(ts), n, t, L.ptr(pts), L.ptr(dirs),
+                                    L.stream()), "ray_points")
+    return pts, dirs
+
+
+def fine_sample(ts_c, t_min, t_max, density_c, count: int, u=None, seed: int = 0, stream_id: int = 1,
+                ray_offset: int = 0, combine: bool = True, eps: float = 1e-8):
+    n, tc = ts_c.shape
+    width = tc + count if combine else count
+    out = torch.empty((n, width), dtype=F32, device=_dev(ts_c))
+    if width == 0:
+        return out
+    if u is not None:
+        assert u.shape == (n, count)
+    L.check(L.lib().lnrf_fine_sample(L.ptr(ts_c), L.ptr(t_min), L.ptr(t_max), L.ptr(density_c), n, tc, count,
+                                     eps, 1 if combine else 0, L.ptr(u), _seed(seed), stream_id, ray_offset,
+                                     L.ptr(out), L.stream()), "fine_sample")
+    return out
+
+
+def termination_probs(ts, t_min, t_max, density):
+    n, t = ts.shape
+    probs = torch.empty((n, t + 1), dtype=F32, device=_dev(ts))
+    L.check(L.lib().lnrf_termination_probs(L.ptr(ts), L.ptr(t_min), L.ptr(t_max), L.ptr(density), n, t,
+                                           L.ptr(probs), L.stream()), "termination_probs")
+    return probs
+
+
+def composite_fwd(rays, ts, t_min, t_max, mask, density, rgb, background, aux=None, targets=None,
+                  sq_err=None, want_coords: bool = True):
+    """-> outputs[N,3], alphas[N], coords[N,3] | None, aux_sum[N,n_aux] | None."""
+    n, t = ts.shape
+    dev = _dev(ts)
+    n_aux = 0 if aux is None else aux.shape[-1]
+    outputs = torch.empty((n, 3), dtype=F32, device=dev)
+    alphas = torch.empty(n, dtype=F32, device=dev)
+    coords = torch.empty((n, 3), dtype=F32, device=dev) if (want_coords and rays is not None) else None
+    aux_sum = torch.empty((n, n_aux), dtype=F32, device=dev) if n_aux else None
+    tstride = 0
+    tptr = None
+    if targets is not None:
+        # targets may be a strided view batch[:, 2] of an [N,3,3] batch
+        assert targets.shape == (n, 3) and targets.stride(1) == 1
+        tstride = targets.stride(0)
+        tptr = L.c_void_p(targets.data_ptr())
+    L.check(L.lib().lnrf_composite_fwd(
+        L.ptr(rays) if rays is not None else None, _ray_stride(rays) if rays is not None else 6, L.ptr(ts),
+        L.ptr(t_min), L.ptr(t_max), L.ptr(mask, torch.uint8), L.ptr(density), L.ptr(rgb), L.ptr(aux), n_aux,
+        L.ptr(background), n, t, L.ptr(outputs), L.ptr(alphas), L.ptr(coords), L.ptr(aux_sum), tptr, tstride,
+        L.ptr(sq_err), L.stream()), "composite_fwd")
+    return outputs, alphas, coords, aux_sum
+
+
+def composite_bwd(ts, t_min, t_max, mask, density, rgb, background, g_background, g_out=None, outputs=None,
+                  targets=None, out_scale: float = 0.0, aux=None, g_aux_w: Sequence[float] = ()):
+    """-> g_density[N,T], g_rgb[N,T,3], g_aux | None; accumulates into g_background[3]."""
+    n, t = ts.shape
+    dev = _dev(ts)
+    n_aux = 0 if aux is None else aux.shape[-1]
+    g_density = torch.empty((n, t), dtype=F32, device=dev)
+    g_rgb = torch.empty((n, t, 3), dtype=F32, device=dev)
+    g_aux = torch.empty((n, t, n_aux), dtype=F32, device=dev) if n_aux else None
+    tstride, tptr = 0, None
+    if targets is not None:
+        assert targets.shape == (n, 3) and targets.stride(1) == 1
+        tstride = targets.stride(0)
+        tptr = L.c_void_p(targets.data_ptr())
+    gw = (L.c_float * 4)(*([float(x) for x in g_aux_w] + [0.0] * (4 - len(g_aux_w))))
+    L.check(L.lib().lnrf_composite_bwd(
+        L.ptr(ts), L.ptr(t_min), L.ptr(t_max), L.ptr(mask, torch.uint8), L.ptr(density), L.ptr(rgb),
+        L.ptr(aux), n_aux, L.ptr(background), n, t, L.ptr(g_out), L.ptr(outputs), tptr, tstride,
+        float(out_scale), gw, L.ptr(g_density), L.ptr(g_rgb), L.ptr(g_aux), L.ptr(g_background), L.stream()),
+        "composite_bwd")
+    return g_density, g_rgb, g_aux
+
+
+# ---------------------------------------------------------------- generic dense (exact fp32)
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D view"
+    return t.stride(0)
+
+
+def _vptr(t: torch.Tensor):
+    """pointer of a possibly column-sliced row-major view"""
+    assert t.is_cuda and t.dtype == F32
+    return L.c_void_p(t.data_ptr())
+
+
+def sinusoidal_emb_into(x: torch.Tensor, freqs: int, out: torch.Tensor, col_off: int = 0):
+    m, dims = x.shape
+    L.check(L.lib().lnrf_sinusoidal_emb(_vptr(x), _ld(x), m, dims, freqs, _vptr(out), _ld(out), col_off,
+                                        L.stream()), "sinusoidal_emb")
+    return out
+
+
+def dense_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    m, k = x.shape
+    k2, n = w.shape
+    assert k == k2 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((m, n), dtype=F32, device=_dev(x))
+    L.check(L.lib().lnrf_dense_fwd(_vptr(x), _ld(x), L.ptr(w), L.ptr(b), act, _vptr(out), _ld(out), m, k, n,
+                                   L.stream()), "dense_fwd")
+    return out
+
+
+def act_bwd_(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
+    m, n = g.shape
+    L.check(L.lib().lnrf_act_bwd(_vptr(g), _ld(g), _vptr(y), _ld(y), act, m, n, L.stream()), "act_bwd")
+    return g
+
+
+def dense_bwd_input(gy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
+                    accumulate: bool = False) -> torch.Tensor:
+    m, n = gy.shape
+    k, n2 = w.shape
+    assert n == n2
+    if out is None:
+        out = torch.empty((m, k), dtype=F32, device=_dev(gy))
+        accumulate = False
+    L.check(L.lib().lnrf_dense_bwd_input(_vptr(gy), _ld(gy), L.ptr(w), _vptr(out), _ld(out),
+                                         1 if accumulate else 0, m, k, n, L.stream()), "dense_bwd_input")
+    return out
+
+
+def dense_bwd_weight(x: torch.Tensor, gy: torch.Tensor, gw: torch.Tensor, gb: Optional[torch.Tensor]):
+    m, k = x.shape
+    m2, n = gy.shape
+    assert m == m2 and gw.shape == (k, n) and gw.is_contiguous()
+    L.check(L.lib().lnrf_dense_bwd_weight(_vptr(x), _ld(x), _vptr(gy), _ld(gy), L.ptr(gw), L.ptr(gb), m, k, n,
+                                          L.stream()), "dense_bwd_weight")
+
+
+# ---------------------------------------------------------------- optimiser
+
+def adam_step_(p, g, m, v, lr, b1, b2, eps, step: int, grad_scale: float = 1.0):
+    L.check(L.lib().lnrf_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, step,
+                                   grad_scale, L.stream()), "adam_step")
+
+
+def sq_norm_into(x: torch.Tensor, out: torch.Tensor):
+    """out (1-element fp32, pre-zeroed by the caller) += sum(x^2)"""
+    L.check(L.lib().lnrf_sq_norm(L.ptr(x), x.numel(), L.ptr(out), L.stream()), "sq_norm")
+    return out
