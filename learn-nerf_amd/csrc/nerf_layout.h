@@ -1,0 +1,200 @@
+// nerf_layout.h — data layout of the fused NeRFModel kernels (default shape only:
+// input_layers=5, mid_layers=4, hidden=256, color=128, x_freqs=10, d_freqs=4; model.py:35-40).
+//
+// Shared by device code (nerf_mlp.hip) and a host build (layout_host.cpp) so that the index
+// maps can be exercised on the CPU by tests/test_nerf_layout.py.
+//
+// Vocabulary
+//   frag   : one MFMA operand for v_mfma_f32_32x32x16_bf16 = 64 lanes x 8 bf16 = 1 KiB.
+//            A-frag lane l (r = l&31, h = l>>5), element j = A[row r][k = 8h + j].
+//            B-frag lane l (c = l&31, h = l>>5), element j = B[k = 8h + j][col c].
+//   k-step : 16 consecutive k of a layer's contraction = one frag per operand.
+//   tile   : 32 evaluations (MFMA columns) handled by one wave.
+//   The f32 result D[32 out rows][32 cols] keeps column c on lane c + 32*hh and row
+//   (q&3) + 8*(q>>2) + 4*hh in register q, so converting registers 8s..8s+7 to bf16 gives the
+//   B-frag of k-step s of the next layer with  k-slot (h, j) <-> feature 16s + 8(j>>2) + 4h + (j&3)
+//   ("hidden" feature order below).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NL_HD __host__ __device__ __forceinline__
+#else
+#define NL_HD inline
+#endif
+
+namespace lnrf {
+namespace nl {
+
+constexpr int kFragBytes = 1024;
+constexpr int kStageFrags = 16;  // frags consumed between two workgroup barriers
+
+// ---- Flax parameter vector (Dense_i.kernel[in,out] row-major, then Dense_i.bias) ----------
+constexpr int kNumDense = 12;
+NL_HD constexpr int dense_in(int l) {
+  return l == 0 ? 60 : (l == 5 ? 316 : (l == 10 ? 280 : (l == 11 ? 128 : 256)));
+}
+NL_HD constexpr int dense_out(int l) { return l == 9 ? 1 : (l == 10 ? 128 : (l == 11 ? 3 : 256)); }
+NL_HD constexpr int dense_w_off(int l) {
+  int off = 0;
+  for (int i = 0; i < l; ++i) off += dense_in(i) * dense_out(i) + dense_out(i);
+  return off;
+}
+NL_HD constexpr int dense_b_off(int l) { return dense_w_off(l) + dense_in(l) * dense_out(l); }
+constexpr int kParamCount = dense_w_off(kNumDense);  // 593,924
+static_assert(kParamCount == 593924, "NeRFModel parameter count");
+
+// ---- k-slot <-> feature maps --------------------------------------------------------------
+// hidden order: slot (ks, h, j) of a tensor produced by the previous MFMA
+NL_HD constexpr int hidden_feat(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// x embedding (60 features, model.py:72-77 order e = 20c + f [sin] / 20c + 10 + f [cos]) lives in
+// 4 k-steps: lane-half h holds 15 (coordinate, frequency) pairs p_global = 15h + p, p = 4ks + (j>>1),
+// element j&1 = {sin, cos}; p == 15 is padding.  Returns -1 for a pad slot.
+NL_HD constexpr int xemb_feat(int ks, int h, int j) {
+  const int p = 4 * ks + (j >> 1);
+  if (p >= 15) return -1;
+  const int pg = 15 * h + p;
+  return 20 * (pg / 10) + (pg % 10) + 10 * (j & 1);
+}
+// d embedding (24 features, e = 8c + f / 8c + 4 + f) lives in 2 k-steps: 6 pairs per lane-half.
+NL_HD constexpr int demb_feat(int ks, int h, int j) {
+  const int p = 4 * ks + (j >> 1);
+  if (p >= 6) return -1;
+  const int pg = 6 * h + p;
+  return 8 * (pg / 4) + (pg % 4) + 4 * (j & 1);
+}
+
+// ---- forward weight stream ------------------------------------------------------------------
+// stream layers: 0..8 = Dense_0..8, 9 = "L10m" (Dense_10 with Dense_9 appended as out row 128),
+// 10 = Dense_11.  Each layer: for out-tile o (32 rows), for k-step ks: one A-frag.
+constexpr int kFwdLayers = 11;
+NL_HD constexpr int fwd_nk(int s) { return s == 0 ? 4 : (s == 5 ? 20 : (s == 9 ? 18 : (s == 10 ? 8 : 16))); }
+NL_HD constexpr int fwd_no(int s) { return s == 9 ? 5 : (s == 10 ? 1 : 8); }
+NL_HD constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
+NL_HD constexpr int fwd_base(int s) {
+  int b = 0;
+  for (int i = 0; i < s; ++i) b += round_up(fwd_nk(i) * fwd_no(i), kStageFrags);
+  return b;
+}
+constexpr int kFwdFrags = fwd_base(kFwdLayers);  // 1200
+static_assert(kFwdFrags == 1200, "forward stream length");
+// fp32 bias block, [stream layer][32*o + row]
+NL_HD constexpr int fwd_bias_base(int s) {
+  int b = 0;
+  for (int i = 0; i < s; ++i) b += 32 * fwd_no(i);
+  return b;
+}
+constexpr int kBiasFloats = fwd_bias_base(kFwdLayers);  // 2496
+static_assert(kBiasFloats == 2496, "bias block");
+
+struct WRef {  // reference to one scalar of the Flax parameter vector; idx < 0 = zero padding
+  int idx;
+};
+
+// weight feeding A-frag element (lane, j) of frag (stream layer s, out-tile o, k-step ks)
+NL_HD constexpr int fwd_weight_index(int s, int o, int ks, int lane, int j) {
+  const int r = lane & 31, h = lane >> 5;
+  if (s == 0) {
+    const int in = xemb_feat(ks, h, j);
+    return in < 0 ? -1 : dense_w_off(0) + in * 256 + (32 * o + r);
+  }
+  if (s <= 8) {
+    int in;
+    if (s == 5 && ks >= 16) {
+      const int e = xemb_feat(ks - 16, h, j);
+      if (e < 0) return -1;
+      in = 256 + e;  // model.py:52 concat([z, x_emb])
+    } else {
+      in = hidden_feat(ks, h, j);
+    }
+    return dense_w_off(s) + in * 256 + (32 * o + r);
+  }
+  if (s == 9) {
+    if (o < 4) {
+      int in;
+      if (ks >= 16) {
+        const int e = demb_feat(ks - 16, h, j);
+        if (e < 0) return -1;
+        in = 256 + e;  // model.py:58 concat([z, d_emb])
+      } else {
+        in = hidden_feat(ks, h, j);
+      }
+      return dense_w_off(10) + in * 128 + (32 * o + r);
+    }
+    // o == 4: row 0 is the density logit (Dense_9, model.py:57); it sees z only
+    if (r != 0 || ks >= 16) return -1;
+    return dense_w_off(9) + hidden_feat(ks, h, j);
+  }
+  // s == 10: Dense_11 (128 -> 3)
+  if (r >= 3) return -1;
+  return dense_w_off(11) + hidden_feat(ks, h, j) * 3 + r;
+}
+
+// parameter index of bias element (stream layer s, row idx = 32*o + r); -1 = zero
+NL_HD constexpr int fwd_bias_index(int s, int row) {
+  if (s <= 8) return dense_b_off(s) + row;
+  if (s == 9) return row < 128 ? dense_b_off(10) + row : (row == 128 ? dense_b_off(9) : -1);
+  return row < 3 ? dense_b_off(11) + row : -1;
+}
+
+// ---- backward (input-gradient) weight stream --------------------------------------------------
+// stream layers t: 0 = Dense_11^T, 1 = L10m^T (z rows only), 2..4 = Dense_8..6^T,
+// 5 = Dense_5^T (h rows only), 6..9 = Dense_4..1^T.   A rows = layer inputs, k = layer outputs.
+constexpr int kBwdLayers = 10;
+NL_HD constexpr int bwd_nk(int t) { return t == 0 ? 1 : (t == 1 ? 9 : 16); }
+NL_HD constexpr int bwd_no(int t) { return t == 0 ? 4 : 8; }
+NL_HD constexpr int bwd_base(int t) {
+  int b = 0;
+  for (int i = 0; i < t; ++i) b += round_up(bwd_nk(i) * bwd_no(i), kStageFrags);
+  return b;
+}
+constexpr int kBwdFrags = bwd_base(kBwdLayers);  // 1120
+static_assert(kBwdFrags == 1120, "backward stream length");
+NL_HD constexpr int bwd_dense(int t) { return t == 0 ? 11 : (t == 1 ? 10 : 10 - t); }  // t=2->8 ... t=9->1
+
+NL_HD constexpr int bwd_weight_index(int t, int o, int ks, int lane, int j) {
+  const int r = lane & 31, h = lane >> 5;
+  const int in = 32 * o + r;  // row of the Flax kernel = input feature
+  if (t == 0) {               // k slot (h=0, j<3) = rgb channel j
+    if (h != 0 || j >= 3) return -1;
+    return dense_w_off(11) + in * 3 + j;
+  }
+  if (t == 1) {
+    if (ks < 8) return dense_w_off(10) + in * 128 + hidden_feat(ks, h, j);
+    if (h == 0 && j == 0) return dense_w_off(9) + in;  // density-logit gradient slot
+    return -1;
+  }
+  const int l = bwd_dense(t);
+  return dense_w_off(l) + in * 256 + hidden_feat(ks, h, j);
+}
+
+// ---- packed parameter blob --------------------------------------------------------------------
+constexpr int64_t kPackFwdOff = 0;
+constexpr int64_t kPackBwdOff = (int64_t)kFwdFrags * kFragBytes;
+constexpr int64_t kPackBiasOff = kPackBwdOff + (int64_t)kBwdFrags * kFragBytes;
+constexpr int64_t kPackBytes = kPackBiasOff + round_up(kBiasFloats * 4, 1024);
+
+// ---- saved activations / gradient dumps -------------------------------------------------------
+// Both buffers are [slot][tile][1 KiB]; a slot is one k-step (16 features) of one tensor.
+// Inside the 1 KiB block lane (c, hh) of frag slot F stores its 16 bytes at dump_lane_off():
+// the permutation makes the transposed LDS reads of the weight-gradient kernel conflict-free.
+NL_HD constexpr int dump_lane_off(int slot, int c, int hh) {
+  return 256 * (c >> 3) + 128 * (((c >> 2) & 1) ^ (slot & 1)) + 64 * hh + 16 * (c & 3);
+}
+// forward save slots
+constexpr int kSaveXin = 0;    // 4 slots
+constexpr int kSaveDin = 4;    // 2 slots
+constexpr int kSaveH = 6;      // h0..h7 (relu outputs of Dense_0..7): 16 slots each
+constexpr int kSaveZ = 6 + 8 * 16;      // z = Dense_8 output (linear): 16 slots
+constexpr int kSaveH10 = kSaveZ + 16;   // relu(Dense_10): 8 slots
+constexpr int kSaveSlots = kSaveH10 + 8;  // 158
+// backward dump slots (pre-activation gradients)
+constexpr int kGradDy11 = 0;            // 2 slots (second is zero padding)
+constexpr int kGradDy10m = 2;           // 10 slots: 8 for Dense_10 outputs, slot 8 = logit, slot 9 zero
+constexpr int kGradDy = 12;             // dy8, dy7, ..., dy0: 16 slots each, index (8 - l)
+constexpr int kGradSlots = kGradDy + 9 * 16;  // 156
+NL_HD constexpr int grad_dy_slot(int l) { return kGradDy + (8 - l) * 16; }
+
+}  // namespace nl
+}  // namespace lnrf

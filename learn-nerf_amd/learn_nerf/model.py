@@ -1,0 +1,289 @@
+"""
+learn_nerf.model — ModelBase, NeRFModel, sinusoidal_emb (reference: learn_nerf/model.py).
+
+Same constructor fields and call pattern as the Flax modules:
+    params = model.init(dict(params=rng), x, d)["params"]
+    density, rgb, aux = model.apply(dict(params=params), x, d)          (render.py:320-324)
+Arrays are torch tensors on the GPU.  NeRFModel has two compute paths, both hand-written HIP:
+  precision="bf16": fused bf16-MFMA kernels (nerf_mlp.hip) — the performance path;
+  precision="fp32": exact-fp32 dense kernels on the f32 MFMA (dense.hip) — parity/any shape.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .params import ParamTree, as_generator, build_tree, default_device, flat_of, lecun_normal_, spec_size
+
+F32 = torch.float32
+
+
+class ModelBase:
+    """
+    Base class used by all NeRF models (model.py:7-27).
+
+    __call__/apply(x[N,3], d[N,3]) -> (density[N,1] >= 0, rgb[N,3] in [-1,1], aux{name: [N]}).
+    Subclasses provide param_spec(), _forward(flat, x, d, rays, ts, save) and _backward(...).
+    """
+
+    def param_spec(self) -> List[Tuple[str, str, Tuple[int, ...]]]:
+        raise NotImplementedError
+
+    def num_params(self) -> int:
+        return spec_size(self.param_spec())
+
+    # ---- Flax-like API ------------------------------------------------------------------
+    def init(self, rngs, x=None, d=None, device=None) -> Dict[str, ParamTree]:
+        """model.init(dict(params=key), x, d) (train.py:49-50): returns {"params": tree}."""
+        rng = rngs["params"] if isinstance(rngs, dict) else rngs
+        device = device if device is not None else default_device()
+        flat = torch.zeros(self.num_params(), dtype=F32)
+        self.init_flat_(flat, as_generator(rng))
+        return {"params": build_tree(flat.to(device), self.param_spec())}
+
+    def init_flat_(self, flat: torch.Tensor, gen: torch.Generator) -> None:
+        raise NotImplementedError
+
+    def tree(self, flat: torch.Tensor) -> ParamTree:
+        return build_tree(flat, self.param_spec())
+
+    def flat(self, params) -> torch.Tensor:
+        return flat_of(params, self.param_spec())
+
+    def apply(self, variables, x: torch.Tensor, d: torch.Tensor):
+        params = variables["params"] if "params" in variables and not _is_leafy(variables) else variables
+        density, rgb, aux, _ = self.forward_points(self.flat(params), x.contiguous(), d.contiguous(), save=False)
+        return density.reshape(-1, 1), rgb, aux
+
+    def __call__(self, x, d):
+        raise NotImplementedError("call model.apply(dict(params=params), x, d)")
+
+    # ---- kernel-facing API (used by render.py / train.py) ------------------------------------
+    def forward_points(self, flat, x, d, save: bool):
+        """-> density[M], rgb[M,3], aux{name: [M]}, ctx"""
+        raise NotImplementedError
+
+    def forward_rays(self, flat, rays, ts, save: bool):
+        """Evaluate at x = o + d*ts without the caller materialising points (render.py:318-319).
+        -> density[N,T], rgb[N,T,3], aux{name: [N,T]}, ctx"""
+        pts, dirs = ops.ray_points(rays, ts)
+        n, t = ts.shape
+        density, rgb, aux, ctx = self.forward_points(flat, pts.view(-1, 3), dirs.view(-1, 3), save)
+        return density.view(n, t), rgb.view(n, t, 3), {k: v.view(n, t) for k, v in aux.items()}, ctx
+
+    def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat) -> None:
+        """grad_flat += d L / d params given gradients wrt the forward outputs."""
+        raise NotImplementedError
+
+
+def _is_leafy(d) -> bool:
+    return any(isinstance(v, torch.Tensor) for v in d.values())
+
+
+def sinusoidal_emb(coords: torch.Tensor, freqs: int) -> torch.Tensor:
+    """
+    Compute sinusoidal embeddings (model.py:65-77): [N x D] -> [N x D*freqs*2], per coordinate
+    [sin(2^0 c) .. sin(2^(F-1) c), cos(2^0 c) .. cos(2^(F-1) c)].
+    """
+    shape = coords.shape
+    x = coords.reshape(-1, shape[-1]).contiguous()
+    out = torch.empty((x.shape[0], shape[-1] * 2 * freqs), dtype=F32, device=x.device)
+    ops.sinusoidal_emb_into(x, freqs, out, 0)
+    return out.reshape(shape[:-1] + (shape[-1] * 2 * freqs,))
+
+
+@dataclass
+class NeRFModel(ModelBase):
+    """
+    A model architecture based directly on Mildenhall et al. (2020) (model.py:30-62).
+    """
+
+    input_layers: int = 5
+    mid_layers: int = 4
+    hidden_dim: int = 256
+    color_layer_dim: int = 128
+    x_freqs: int = 10
+    d_freqs: int = 4
+    precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
+
+    _pack_cache: Any = field(default=None, repr=False, compare=False)
+
+    # ---- structure ---------------------------------------------------------------------------
+    def layer_dims(self) -> List[Tuple[int, int]]:
+        xe, de = 6 * self.x_freqs, 6 * self.d_freqs
+        dims, fan = [], xe
+        for _ in range(self.input_layers):
+            dims.append((fan, self.hidden_dim))
+            fan = self.hidden_dim
+        fan = self.hidden_dim + xe
+        for _ in range(self.mid_layers):
+            dims.append((fan, self.hidden_dim))
+            fan = self.hidden_dim
+        dims.append((self.hidden_dim, 1))
+        dims.append((self.hidden_dim + de, self.color_layer_dim))
+        dims.append((self.color_layer_dim, 3))
+        return dims
+
+    def param_spec(self):
+        spec = []
+        for i, (fi, fo) in enumerate(self.layer_dims()):
+            spec.append((f"Dense_{i}", "kernel", (fi, fo)))
+            spec.append((f"Dense_{i}", "bias", (fo,)))
+        return spec
+
+    def init_flat_(self, flat, gen):
+        off = 0
+        for fi, fo in self.layer_dims():
+            lecun_normal_(flat[off:off + fi * fo].view(fi, fo), fi, gen)
+            off += fi * fo + fo  # bias stays zero (Flax default)
+
+    def _shape_struct(self) -> L.NerfShape:
+        return L.NerfShape(self.input_layers, self.mid_layers, self.hidden_dim, self.color_layer_dim,
+                           self.x_freqs, self.d_freqs)
+
+    def fused_supported(self) -> bool:
+        return (self.input_layers, self.mid_layers, self.hidden_dim, self.color_layer_dim, self.x_freqs,
+                self.d_freqs) == (5, 4, 256, 128, 10, 4)
+
+    def _use_fused(self) -> bool:
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError(f"unknown precision {self.precision!r}")
+        return self.precision == "bf16" and self.fused_supported()
+
+    # ---- fused bf16 path ----------------------------------------------------------------------
+    def packed_weights(self, flat: torch.Tensor) -> torch.Tensor:
+        """bf16 MFMA-fragment copy of the parameters; rebuilt when the flat buffer changes."""
+        key = (flat.data_ptr(), flat._version, flat.device)
+        if self._pack_cache is not None and self._pack_cache[0] == key:
+            return self._pack_cache[1]
+        shape = self._shape_struct()
+        nbytes = L.lib().lnrf_nerf_packed_bytes(ctypes.byref(shape))
+        packed = (self._pack_cache[1] if self._pack_cache is not None and self._pack_cache[1].device == flat.device
+                  else torch.empty(nbytes, dtype=torch.uint8, device=flat.device))
+        L.check(L.lib().lnrf_nerf_pack_weights(ctypes.byref(shape), L.ptr(flat), L.ptr(packed, torch.uint8),
+                                               L.stream()), "nerf_pack_weights")
+        self._pack_cache = (key, packed)
+        return packed
+
+    def _fused_fwd(self, flat, m, save, x=None, d=None, rays=None, ts=None):
+        shape = self._shape_struct()
+        packed = self.packed_weights(flat)
+        dev = flat.device
+        density = torch.empty(m, dtype=F32, device=dev)
+        rgb = torch.empty((m, 3), dtype=F32, device=dev)
+        save_buf = None
+        if save:
+            nbytes = L.lib().lnrf_nerf_save_bytes(ctypes.byref(shape), m)
+            save_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if rays is not None:
+            rstride, t = rays.shape[1] * 3, ts.shape[1]
+        else:
+            rstride, t = 6, 0
+        L.check(L.lib().lnrf_nerf_mlp_fwd(
+            ctypes.byref(shape), L.ptr(packed, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride, L.ptr(ts),
+            t, m, L.ptr(density), L.ptr(rgb), L.ptr(save_buf, torch.uint8), L.stream()), "nerf_mlp_fwd")
+        ctx = dict(kind="fused", packed=packed, save=save_buf, density=density, rgb=rgb, m=m) if save else None
+        return density, rgb, ctx
+
+    def forward_points(self, flat, x, d, save: bool):
+        m = x.shape[0]
+        if self._use_fused():
+            density, rgb, ctx = self._fused_fwd(flat, m, save, x=x, d=d)
+            return density, rgb, {}, ctx
+        return self._dense_fwd(flat, x, d, save)
+
+    def forward_rays(self, flat, rays, ts, save: bool):
+        if self._use_fused():
+            n, t = ts.shape
+            density, rgb, ctx = self._fused_fwd(flat, n * t, save, rays=rays, ts=ts)
+            return density.view(n, t), rgb.view(n, t, 3), {}, ctx
+        return super().forward_rays(flat, rays, ts, save)
+
+    def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+        if ctx["kind"] == "fused":
+            shape = self._shape_struct()
+            m = ctx["m"]
+            nbytes = L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=grad_flat.device)
+            L.check(L.lib().lnrf_nerf_mlp_bwd(
+                ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
+                L.ptr(ctx["density"]), L.ptr(ctx["rgb"]), L.ptr(g_density.reshape(-1)),
+                L.ptr(g_rgb.reshape(-1, 3)), m, L.ptr(scratch, torch.uint8), L.ptr(grad_flat), L.stream()),
+                "nerf_mlp_bwd")
+            return
+        self._dense_bwd(ctx, g_density, g_rgb, grad_flat)
+
+    # ---- exact fp32 dense path (any shape) ------------------------------------------------------
+    def _dense_fwd(self, flat, x, d, save: bool):
+        tree = self.tree(flat)
+        W = [(tree[f"Dense_{i}"]["kernel"], tree[f"Dense_{i}"]["bias"]) for i in range(len(self.layer_dims()))]
+        m, dev, hd = x.shape[0], flat.device, self.hidden_dim
+        xe_w, de_w = 6 * self.x_freqs, 6 * self.d_freqs
+        cat_x = torch.empty((m, hd + xe_w), dtype=F32, device=dev)  # [z, x_emb] (model.py:52)
+        ops.sinusoidal_emb_into(x, self.x_freqs, cat_x, hd)
+        x_emb = cat_x[:, hd:]
+        acts = []
+        z = x_emb
+        li = 0
+        for i in range(self.input_layers):  # model.py:50-51
+            out = cat_x[:, :hd] if i == self.input_layers - 1 else None
+            z = ops.dense_fwd(z, W[li][0], W[li][1], L.ACT_RELU, out=out)
+            acts.append(z)
+            li += 1
+        cat_d = torch.empty((m, hd + de_w), dtype=F32, device=dev)  # [z, d_emb] (model.py:58)
+        ops.sinusoidal_emb_into(d, self.d_freqs, cat_d, hd)
+        z = cat_x
+        for i in range(self.mid_layers):  # model.py:53-56: relu precedes Dense for i > 0
+            last = i == self.mid_layers - 1
+            z = ops.dense_fwd(z, W[li][0], W[li][1], L.ACT_NONE if last else L.ACT_RELU,
+                              out=cat_d[:, :hd] if last else None)
+            acts.append(z)
+            li += 1
+        density = ops.dense_fwd(cat_d[:, :hd], W[li][0], W[li][1], L.ACT_SOFTPLUS)  # model.py:57
+        li += 1
+        h_col = ops.dense_fwd(cat_d, W[li][0], W[li][1], L.ACT_RELU)  # model.py:59
+        li += 1
+        rgb = ops.dense_fwd(h_col, W[li][0], W[li][1], L.ACT_TANH)  # model.py:60
+        ctx = None
+        if save:
+            ctx = dict(kind="dense", flat=flat, cat_x=cat_x, cat_d=cat_d, acts=acts, h_col=h_col,
+                       density=density, rgb=rgb)
+        return density.view(-1), rgb, {}, ctx
+
+    def _dense_bwd(self, ctx, g_density, g_rgb, grad_flat):
+        tree, gtree = self.tree(ctx["flat"]), self.tree(grad_flat)
+        nl = len(self.layer_dims())
+        W = [tree[f"Dense_{i}"]["kernel"] for i in range(nl)]
+        G = [(gtree[f"Dense_{i}"]["kernel"], gtree[f"Dense_{i}"]["bias"]) for i in range(nl)]
+        hd = self.hidden_dim
+        cat_x, cat_d, acts, h_col = ctx["cat_x"], ctx["cat_d"], ctx["acts"], ctx["h_col"]
+        i_rgb, i_col, i_den = nl - 1, nl - 2, nl - 3
+        gy = ops.act_bwd_(g_rgb.reshape(-1, 3).clone(), ctx["rgb"], L.ACT_TANH)
+        ops.dense_bwd_weight(h_col, gy, *G[i_rgb])
+        gh = ops.dense_bwd_input(gy, W[i_rgb])
+        gy = ops.act_bwd_(gh, h_col, L.ACT_RELU)
+        ops.dense_bwd_weight(cat_d, gy, *G[i_col])
+        gz = ops.dense_bwd_input(gy, W[i_col][:hd])
+        gd = ops.act_bwd_(g_density.reshape(-1, 1).clone(), ctx["density"], L.ACT_SOFTPLUS)
+        z_view = cat_d[:, :hd]
+        ops.dense_bwd_weight(z_view, gd, *G[i_den])
+        ops.dense_bwd_input(gd, W[i_den], out=gz, accumulate=True)
+        gy = gz  # Dense_{last mid} output is linear
+        li = i_den - 1
+        for i in reversed(range(self.mid_layers)):
+            inp = cat_x if i == 0 else acts[self.input_layers + i - 1]
+            ops.dense_bwd_weight(inp, gy, *G[li])
+            gh = ops.dense_bwd_input(gy, W[li][:hd])
+            prev = cat_x[:, :hd] if i == 0 else acts[self.input_layers + i - 1]
+            gy = ops.act_bwd_(gh, prev, L.ACT_RELU)
+            li -= 1
+        for i in reversed(range(self.input_layers)):
+            inp = cat_x[:, hd:] if i == 0 else acts[i - 1]
+            ops.dense_bwd_weight(inp, gy, *G[li])
+            if i > 0:
+                gh = ops.dense_bwd_input(gy, W[li])
+                gy = ops.act_bwd_(gh, acts[i - 1], L.ACT_RELU)
+            li -= 1

@@ -127,25 +127,33 @@ def test_fine_sample(n, tc, tf):
     s = oracle_samples(rays, tc, u)
     dens = (torch.rand(n, tc, generator=gen) ** 4 * 30).float()
     dens[:, : tc // 3] = 0.0  # empty space in front: flat CDF segments
-    ref = s.fine_sampling(tf, uf.double(), dens.double())
     g = lambda x: x.cuda()
     t_min, t_max, mask, ts = ops.ray_aabb_stratified(g(rays), BBOX_MIN, BBOX_MAX, tc, u=g(u))
     out = ops.fine_sample(ts, t_min, t_max, g(dens), tf, u=g(uf))
     assert out.shape == (n, tc + tf)
-    o = out.cpu().double()
+    o = out.cpu()
     assert (o[:, 1:] >= o[:, :-1]).all(), "fine samples must be sorted (render.py:255)"
-    # fp32 inverse-CDF vs float64 oracle: positions agree to 1e-4 of the ray span
+    new_only = ops.fine_sample(ts, t_min, t_max, g(dens), tf, u=g(uf), combine=False).cpu()
+    # combine == exact sort of [coarse ts, new ts] (render.py:253-255): bit-exact check
+    assert torch.equal(o, torch.sort(torch.cat([ts.cpu(), new_only], 1), 1).values)
+    if tf == 0:
+        return
+    # Inverse-CDF sampling is ill-conditioned in t wherever the coarse CDF is flat (the float32 and
+    # float64 oracles themselves differ by >1e-3 of the span there), so parity is checked in CDF
+    # space: F(t_new) must reproduce the stratified u' to 2e-6, F = float64 oracle CDF.
+    w = s.termination_probs(dens.double())[:, :-1] + 1e-8
+    xs = torch.cat([torch.zeros(n, 1, dtype=F64), torch.cumsum(w, 1)], 1)
+    xs = xs / xs[:, -1:]
+    ys = torch.cat([s.t_min[:, None], s.ends()], 1)
+    up = (torch.arange(tf, dtype=F64)[None] + uf.double()) / tf
+    f_at = OR.interp_rows(new_only.double(), ys, xs)
+    assert (f_at - up).abs().max().item() <= 2e-6
+    assert (new_only.double() >= s.t_min[:, None] - 1e-6).all() and (new_only.double() <= s.t_max[:, None] + 1e-6).all()
+    # and in well-conditioned rays (dense medium) positions agree directly with the oracle
+    ref_new = s.fine_sampling(tf, uf.double(), dens.double(), combine=False).ts
     span = (s.t_max - s.t_min)[:, None]
-    assert ((o - ref.ts).abs() <= 1e-4 * span + 1e-6).all()
-    # coarse samples are a subset (bit-exact fp32 values)
-    oc = out.cpu().numpy()
-    tc_np = ts.cpu().numpy()
-    for i in range(n):
-        assert np.isin(tc_np[i], oc[i]).all()
-    if tf > 0:
-        new_only = ops.fine_sample(ts, t_min, t_max, g(dens), tf, u=g(uf), combine=False)
-        ref_new = s.fine_sampling(tf, uf.double(), dens.double(), combine=False).ts
-        assert ((new_only.cpu().double() - ref_new).abs() <= 1e-4 * span + 1e-6).all()
+    frac_close = ((new_only.double() - ref_new).abs() <= 1e-4 * span + 1e-6).double().mean().item()
+    assert frac_close > 0.99
 
 
 @pytest.mark.parametrize("n,t,n_aux", [(40, 64, 0), (33, 192, 2), (7, 70, 1)])
