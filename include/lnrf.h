@@ -80,6 +80,10 @@ int lnrf_fine_sample(const float* ts_c, const float* t_min, const float* t_max,
                      int32_t combine, const float* u, uint64_t seed, uint32_t stream_id,
                      int64_t ray_offset, float* ts_out, lnrf_stream_t stream);
 
+/* RaySamples.starts / ends (render.py:259-265): bin edges [N,T] each (either may be NULL). */
+int lnrf_bin_edges(const float* ts, const float* t_min, const float* t_max, int64_t n_rays,
+                   int32_t t, float* starts, float* ends, lnrf_stream_t stream);
+
 /* RaySamples.termination_probs (render.py:270-287): probs [N, T+1]. */
 int lnrf_termination_probs(const float* ts, const float* t_min, const float* t_max,
                            const float* density, int64_t n_rays, int32_t t, float* probs,
@@ -172,11 +176,22 @@ int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packed, const fl
                       lnrf_stream_t stream);
 
 /* Backward of the above wrt the parameters: grads[param_count] += d L / d params given
- * g_density[M], g_rgb[M,3] (= d L / d outputs), the forward outputs and the save buffer. */
+ * g_density[M], g_rgb[M,3] (= d L / d outputs), the forward outputs and the save buffer.
+ * Equals lnrf_nerf_mlp_bwd_chain followed by lnrf_nerf_mlp_bwd_weights. */
 int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packed, const void* save,
                       const float* density, const float* rgb, const float* g_density,
                       const float* g_rgb, int64_t m, void* scratch, float* grads,
                       lnrf_stream_t stream);
+
+/* Part 1: input-gradient chain (what jax.grad does through model.py:49-60 back to front);
+ * writes the pre-activation gradients of every Dense layer into scratch (fragment order). */
+int lnrf_nerf_mlp_bwd_chain(const lnrf_nerf_shape* shape, const void* packed, const void* save,
+                            const float* density, const float* rgb, const float* g_density,
+                            const float* g_rgb, int64_t m, void* scratch, lnrf_stream_t stream);
+
+/* Part 2: grads += X_l^T dy_l for every Dense kernel and sum_m dy_l for every bias. */
+int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
+                              int64_t m, float* grads, lnrf_stream_t stream);
 
 /* ------------------------------------------------------------- optimiser ---- */
 

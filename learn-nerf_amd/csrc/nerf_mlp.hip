@@ -794,15 +794,14 @@ extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packe
   return LNRF_OK;
 }
 
-extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packed, const void* save,
-                                 const float* density, const float* rgb, const float* g_density,
-                                 const float* g_rgb, int64_t m, void* scratch, float* grads,
-                                 lnrf_stream_t stream) {
+extern "C" int lnrf_nerf_mlp_bwd_chain(const lnrf_nerf_shape* shape, const void* packed, const void* save,
+                                       const float* density, const float* rgb, const float* g_density,
+                                       const float* g_rgb, int64_t m, void* scratch, lnrf_stream_t stream) {
   if (!shape_supported(shape)) {
-    set_error("lnrf_nerf_mlp_bwd: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
+    set_error("lnrf_nerf_mlp_bwd_chain: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
     return LNRF_ERR_UNSUPPORTED;
   }
-  LNRF_CHECK_ARG(packed && save && density && rgb && g_density && g_rgb && scratch && grads, "null pointer");
+  LNRF_CHECK_ARG(packed && save && density && rgb && g_density && g_rgb && scratch, "null pointer");
   LNRF_CHECK_ARG(m >= 0, "bad m");
   if (m == 0) return LNRF_OK;
   const int64_t n_tiles = tiles_for(m);
@@ -813,7 +812,30 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
                      kFusedLds, st, (const char*)packed, (const char*)save, density, rgb, g_density, g_rgb, m,
                      n_tiles, (char*)scratch);
   LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
 
+extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packed, const void* save,
+                                 const float* density, const float* rgb, const float* g_density,
+                                 const float* g_rgb, int64_t m, void* scratch, float* grads,
+                                 lnrf_stream_t stream) {
+  int rc = lnrf_nerf_mlp_bwd_chain(shape, packed, save, density, rgb, g_density, g_rgb, m, scratch, stream);
+  if (rc) return rc;
+  return lnrf_nerf_mlp_bwd_weights(shape, save, scratch, m, grads, stream);
+}
+
+extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
+                                         int64_t m, float* grads, lnrf_stream_t stream) {
+  if (!shape_supported(shape)) {
+    set_error("lnrf_nerf_mlp_bwd_weights: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
+    return LNRF_ERR_UNSUPPORTED;
+  }
+  LNRF_CHECK_ARG(save && scratch && grads, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = tiles_for(m);
+  hipStream_t st = as_stream(stream);
+  int rc;
   // weight-gradient problems, one launch per operand shape
   auto mk = [&](int xs, int ys, int dense, int row_map, int row_off, int col_map, int do_bias) {
     WgradProblem p;

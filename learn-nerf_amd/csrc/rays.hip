@@ -433,6 +433,21 @@ __global__ void fine_sample_kernel(const float* __restrict__ ts_c, const float* 
   }
 }
 
+// RaySamples.starts / ends (render.py:259-265)
+__global__ void bin_edges_kernel(const float* __restrict__ ts, const float* __restrict__ t_min,
+                                 const float* __restrict__ t_max, int64_t n_rays, int T,
+                                 float* __restrict__ starts, float* __restrict__ ends) {
+  const int64_t total = n_rays * T;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = e / T;
+    const int i = (int)(e - n * T);
+    const float t_i = ts[e];
+    if (starts) starts[e] = i == 0 ? t_min[n] : (t_i + ts[e - 1]) / 2.0f;
+    if (ends) ends[e] = i == T - 1 ? t_max[n] : (ts[e + 1] + t_i) / 2.0f;
+  }
+}
+
 }  // namespace lnrf
 
 using namespace lnrf;
@@ -566,6 +581,17 @@ extern "C" int lnrf_fine_sample(const float* ts_c, const float* t_min, const flo
   hipLaunchKernelGGL(fine_sample_kernel, dim3((unsigned)((n_rays + wpb - 1) / wpb)), dim3(wpb * 64),
                      lds, as_stream(stream), ts_c, t_min, t_max, density_c, n_rays, tc, tf, eps,
                      combine, u, seed, stream_id, ray_offset, ts_out);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_bin_edges(const float* ts, const float* t_min, const float* t_max, int64_t n_rays,
+                              int32_t t, float* starts, float* ends, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(ts && t_min && t_max, "null pointer");
+  LNRF_CHECK_ARG(n_rays >= 0 && t >= 0, "bad sizes");
+  if (n_rays == 0 || t == 0) return LNRF_OK;
+  hipLaunchKernelGGL(bin_edges_kernel, dim3(grid_for(n_rays * t, 256)), dim3(256), 0, as_stream(stream), ts,
+                     t_min, t_max, n_rays, t, starts, ends);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }

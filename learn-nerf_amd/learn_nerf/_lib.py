@@ -34,6 +34,7 @@ PROTOTYPES = {
     "lnrf_ray_points": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "lnrf_fine_sample": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P,
                                    c_uint64, c_uint32, c_int64, _P, _P]),
+    "lnrf_bin_edges": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "lnrf_termination_probs": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "lnrf_composite_fwd": (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32,
                                      _P, _P, _P, _P, _P, c_int64, _P, _P]),
@@ -52,6 +53,8 @@ PROTOTYPES = {
     "lnrf_nerf_mlp_fwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, c_int64, _P, c_int32, c_int64, _P, _P,
                                     _P, _P]),
     "lnrf_nerf_mlp_bwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_nerf_mlp_bwd_chain": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "lnrf_nerf_mlp_bwd_weights": (c_int32, [POINTER(NerfShape), _P, _P, c_int64, _P, _P]),
     "lnrf_adam_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
                                  c_float, _P]),
     "lnrf_sq_norm": (c_int32, [_P, c_int64, _P, _P]),

@@ -15,6 +15,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib as L
+from . import _prof
 from . import ops
 from .params import ParamTree, as_generator, build_tree, default_device, flat_of, lecun_normal_, spec_size
 
@@ -108,8 +109,14 @@ class NeRFModel(ModelBase):
     x_freqs: int = 10
     d_freqs: int = 4
     precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
+    tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
 
     _pack_cache: Any = field(default=None, repr=False, compare=False)
+    _pack_generation: int = field(default=0, repr=False, compare=False)
+
+    def invalidate_packed(self) -> None:
+        """Call after the parameters were modified outside torch (e.g. by lnrf_adam_step)."""
+        self._pack_generation += 1
 
     # ---- structure ---------------------------------------------------------------------------
     def layer_dims(self) -> List[Tuple[int, int]]:
@@ -156,7 +163,7 @@ class NeRFModel(ModelBase):
     # ---- fused bf16 path ----------------------------------------------------------------------
     def packed_weights(self, flat: torch.Tensor) -> torch.Tensor:
         """bf16 MFMA-fragment copy of the parameters; rebuilt when the flat buffer changes."""
-        key = (flat.data_ptr(), flat._version, flat.device)
+        key = (flat.data_ptr(), flat._version, flat.device, self._pack_generation)
         if self._pack_cache is not None and self._pack_cache[0] == key:
             return self._pack_cache[1]
         shape = self._shape_struct()
@@ -182,10 +189,13 @@ class NeRFModel(ModelBase):
             rstride, t = rays.shape[1] * 3, ts.shape[1]
         else:
             rstride, t = 6, 0
-        L.check(L.lib().lnrf_nerf_mlp_fwd(
-            ctypes.byref(shape), L.ptr(packed, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride, L.ptr(ts),
-            t, m, L.ptr(density), L.ptr(rgb), L.ptr(save_buf, torch.uint8), L.stream()), "nerf_mlp_fwd")
-        ctx = dict(kind="fused", packed=packed, save=save_buf, density=density, rgb=rgb, m=m) if save else None
+        with _prof.section(f"{self.tag}_fwd"):
+            L.check(L.lib().lnrf_nerf_mlp_fwd(
+                ctypes.byref(shape), L.ptr(packed, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride,
+                L.ptr(ts), t, m, L.ptr(density), L.ptr(rgb), L.ptr(save_buf, torch.uint8), L.stream()),
+                "nerf_mlp_fwd")
+        ctx = (dict(kind="fused", packed=packed, save=save_buf, density=density, rgb=rgb, m=m, tag=self.tag)
+               if save else None)
         return density, rgb, ctx
 
     def forward_points(self, flat, x, d, save: bool):
@@ -208,11 +218,16 @@ class NeRFModel(ModelBase):
             m = ctx["m"]
             nbytes = L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=grad_flat.device)
-            L.check(L.lib().lnrf_nerf_mlp_bwd(
-                ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
-                L.ptr(ctx["density"]), L.ptr(ctx["rgb"]), L.ptr(g_density.reshape(-1)),
-                L.ptr(g_rgb.reshape(-1, 3)), m, L.ptr(scratch, torch.uint8), L.ptr(grad_flat), L.stream()),
-                "nerf_mlp_bwd")
+            tag = ctx.get("tag", "mlp")
+            with _prof.section(f"{tag}_bwd_chain"):
+                L.check(L.lib().lnrf_nerf_mlp_bwd_chain(
+                    ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
+                    L.ptr(ctx["density"]), L.ptr(ctx["rgb"]), L.ptr(g_density.reshape(-1)),
+                    L.ptr(g_rgb.reshape(-1, 3)), m, L.ptr(scratch, torch.uint8), L.stream()), "nerf_mlp_bwd_chain")
+            with _prof.section(f"{tag}_bwd_weights"):
+                L.check(L.lib().lnrf_nerf_mlp_bwd_weights(
+                    ctypes.byref(shape), L.ptr(ctx["save"], torch.uint8), L.ptr(scratch, torch.uint8), m,
+                    L.ptr(grad_flat), L.stream()), "nerf_mlp_bwd_weights")
             return
         self._dense_bwd(ctx, g_density, g_rgb, grad_flat)
 

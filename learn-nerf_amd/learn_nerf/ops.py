@@ -77,6 +77,15 @@ def fine_sample(ts_c, t_min, t_max, density_c, count: int, u=None, seed: int = 0
     return out
 
 
+def bin_edges(ts, t_min, t_max):
+    n, t = ts.shape
+    starts = torch.empty((n, t), dtype=F32, device=_dev(ts))
+    ends = torch.empty((n, t), dtype=F32, device=_dev(ts))
+    L.check(L.lib().lnrf_bin_edges(L.ptr(ts), L.ptr(t_min), L.ptr(t_max), n, t, L.ptr(starts), L.ptr(ends),
+                                   L.stream()), "bin_edges")
+    return starts, ends
+
+
 def termination_probs(ts, t_min, t_max, density):
     n, t = ts.shape
     probs = torch.empty((n, t + 1), dtype=F32, device=_dev(ts))

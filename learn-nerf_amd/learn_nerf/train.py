@@ -1,0 +1,280 @@
+"""
+learn_nerf.train — TrainLoop, default_loss_weights (reference: learn_nerf/train.py).
+
+One step = TrainLoop.step_fn's jitted function (train.py:85-106) restated as an explicit
+sequence of HIP kernel families on one stream:
+  ray/bbox + stratified -> coarse MLP -> composite -> hierarchical resample -> fine MLP ->
+  composite -> [loss gradient fused into] composite backward -> MLP backward (both models) ->
+  [RCCL all-reduce of the flat gradient when torch.distributed is initialised] ->
+  grad/param norms -> fused Adam.
+Parameters {coarse, fine, background} are views of ONE flat fp32 buffer; so are the gradients
+and the Adam moments.
+"""
+import os
+import pickle
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, Optional, Sequence
+
+import torch
+
+from . import _prof
+from . import ops
+from .model import ModelBase
+from .params import ParamTree, as_generator, build_tree, default_device, split_seed
+from .render import STREAM_COARSE, STREAM_FINE, NeRFRenderer, _vec3
+from .rng import Key, KeyLike, Uniforms, as_key, sampler_args, split
+
+F32 = torch.float32
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+@dataclass
+class TrainState:
+    """Minimal stand-in for flax.training.train_state.TrainState (train.py:51-60)."""
+
+    params: Dict[str, Any]
+    step: int
+    opt_m: torch.Tensor
+    opt_v: torch.Tensor
+
+
+class TrainLoop:
+    """
+    A stateful training loop (train.py:17-184).  Constructor arguments as in the reference;
+    ``init_rng`` is an int seed / torch.Generator instead of a jax key.
+    """
+
+    def __init__(
+        self,
+        coarse: ModelBase,
+        fine: ModelBase,
+        init_rng,
+        lr: float,
+        coarse_ts: int,
+        fine_ts: int,
+        adam_b1: float = 0.9,
+        adam_b2: float = 0.999,
+        adam_eps: float = 1e-7,
+        loss_weights: Dict[str, float] = None,
+        density_penalty: Optional[float] = None,
+        density_penalty_batch_size: int = 128,
+        device=None,
+    ):
+        self.coarse = coarse
+        self.fine = fine
+        if hasattr(coarse, "tag") and hasattr(fine, "tag") and coarse is not fine:
+            coarse.tag, fine.tag = "coarse", "fine"
+        self.coarse_ts = coarse_ts
+        self.fine_ts = fine_ts
+        self.lr, self.adam_b1, self.adam_b2, self.adam_eps = lr, adam_b1, adam_b2, adam_eps
+        self.loss_weights = loss_weights if loss_weights is not None else default_loss_weights()
+        self.density_penalty = density_penalty
+        self.density_penalty_batch_size = density_penalty_batch_size
+        self.device = device if device is not None else default_device()
+
+        # train.py:47-58: split the init key, init both models, background = all black (-1,-1,-1)
+        seed = as_generator(init_rng).initial_seed()
+        coarse_seed, fine_seed = split_seed(seed, 2)
+        self.n_coarse, self.n_fine = coarse.num_params(), fine.num_params()
+        total = self.n_coarse + self.n_fine + 3
+        host = torch.zeros(total, dtype=F32)
+        coarse.init_flat_(host[: self.n_coarse], as_generator(coarse_seed))
+        fine.init_flat_(host[self.n_coarse: self.n_coarse + self.n_fine], as_generator(fine_seed))
+        host[-3:] = -1.0
+        self.flat = host.to(self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.state = TrainState(params=self._views(self.flat), step=0, opt_m=torch.zeros_like(self.flat),
+                                opt_v=torch.zeros_like(self.flat))
+        self._scalars = torch.zeros(8, dtype=F32, device=self.device)
+
+    def _params_changed(self):
+        # the kernels write through raw pointers, which torch's version counters do not see
+        for mdl in (self.coarse, self.fine):
+            if hasattr(mdl, "invalidate_packed"):
+                mdl.invalidate_packed()
+
+    # ---- parameter views ------------------------------------------------------------------------
+    def _slices(self, flat):
+        a, b = self.n_coarse, self.n_coarse + self.n_fine
+        return flat[:a], flat[a:b], flat[b:b + 3]
+
+    def _views(self, flat) -> Dict[str, Any]:
+        c, f, bg = self._slices(flat)
+        return dict(coarse=self.coarse.tree(c), fine=self.fine.tree(f), background=bg)
+
+    # ---- checkpointing (train.py:62-76) ------------------------------------------------------------
+    def save(self, path: str):
+        """Save the model parameters to a file (atomic rename, params only, like the reference)."""
+        tmp_path = path + ".tmp"
+        c, f, bg = self._slices(self.flat)
+        blob = dict(format="lnrf-params-v1",
+                    coarse=_tree_to_host(self.state.params["coarse"]),
+                    fine=_tree_to_host(self.state.params["fine"]),
+                    background=bg.detach().cpu().numpy())
+        with open(tmp_path, "wb") as fh:
+            pickle.dump(blob, fh)
+        os.rename(tmp_path, path)
+
+    def load(self, path: str):
+        """Load the model parameters from a file written by save()."""
+        with open(path, "rb") as fh:
+            blob = pickle.load(fh)
+        c, f, bg = self._slices(self.flat)
+        c.copy_(_tree_from_host(blob["coarse"], self.coarse).to(self.device))
+        f.copy_(_tree_from_host(blob["fine"], self.fine).to(self.device))
+        bg.copy_(torch.as_tensor(blob["background"], dtype=F32).to(self.device))
+        self._params_changed()
+
+    # ---- the step --------------------------------------------------------------------------------
+    def step_fn(self, bbox_min, bbox_max) -> Callable[[KeyLike, torch.Tensor], Dict[str, torch.Tensor]]:
+        """Create a function that steps in place and returns a logging dict (train.py:78-112)."""
+        bmin, bmax = _vec3(bbox_min), _vec3(bbox_max)
+
+        def in_place_step(key: KeyLike, batch: torch.Tensor) -> Dict[str, torch.Tensor]:
+            return self._step(key, bmin, bmax, batch)
+
+        return in_place_step
+
+    def _forward_backward(self, key, bmin, bmax, batch, params_flat, grad_flat, want_grad: bool):
+        """losses (train.py:114-165) and, if want_grad, d total / d params accumulated into grad_flat."""
+        n = batch.shape[0]
+        dist = _dist()
+        world = dist.get_world_size() if dist else 1
+        c_flat, f_flat, bg = self._slices(params_flat)
+        sc = self._scalars
+        sc.zero_()
+        render_key, density_key = split(key, 2)  # train.py:137
+        coarse_key, fine_key = split(render_key, 2)  # render.py:55
+        targets = batch[:, 2]
+
+        t_min, t_max, mask, ts_c = ops.ray_aabb_stratified(batch, bmin, bmax, self.coarse_ts,
+                                                           **sampler_args(coarse_key, STREAM_COARSE))
+        dens_c, rgb_c, aux_c, ctx_c = self.coarse.forward_rays(c_flat, batch, ts_c, save=want_grad)
+        names_c = list(aux_c.keys())
+        auxs_c = torch.stack([aux_c[k] for k in names_c], -1).contiguous() if names_c else None
+        out_c, _, _, asum_c = ops.composite_fwd(None, ts_c, t_min, t_max, mask, dens_c, rgb_c, bg, aux=auxs_c,
+                                                targets=targets, sq_err=sc[0:1], want_coords=False)
+        ts_f = ops.fine_sample(ts_c, t_min, t_max, dens_c, self.fine_ts, **sampler_args(fine_key, STREAM_FINE))
+        dens_f, rgb_f, aux_f, ctx_f = self.fine.forward_rays(f_flat, batch, ts_f, save=want_grad)
+        names_f = list(aux_f.keys())
+        auxs_f = torch.stack([aux_f[k] for k in names_f], -1).contiguous() if names_f else None
+        out_f, _, _, asum_f = ops.composite_fwd(None, ts_f, t_min, t_max, mask, dens_f, rgb_f, bg, aux=auxs_f,
+                                                targets=targets, sq_err=sc[1:2], want_coords=False)
+
+        inv = 1.0 / (3.0 * n)
+        loss_dict = dict(coarse=sc[0] * inv, fine=sc[1] * inv)  # train.py:141-144
+        for prefix, names, asum in (("coarse", names_c, asum_c), ("fine", names_f, asum_f)):
+            if names:
+                means = asum.mean(dim=0)
+                for i, k in enumerate(names):
+                    loss_dict[f"{prefix}_{k}"] = means[i]  # train.py:146-151
+
+        if want_grad:
+            gc, gf, gbg = self._slices(grad_flat)
+            out_scale = 2.0 * inv  # d mean((out-t)^2) / d out
+            for (ts, dens, rgb, out, model, ctx, gslice, names, auxs) in (
+                (ts_c, dens_c, rgb_c, out_c, self.coarse, ctx_c, gc, names_c, auxs_c),
+                (ts_f, dens_f, rgb_f, out_f, self.fine, ctx_f, gf, names_f, auxs_f),
+            ):
+                gw = [self.loss_weights[k] / n for k in names]
+                gd, grgb, gaux = ops.composite_bwd(ts, t_min, t_max, mask, dens, rgb, bg, gbg, outputs=out,
+                                                   targets=targets, out_scale=out_scale, aux=auxs, g_aux_w=gw)
+                g_aux = {k: gaux[..., i] for i, k in enumerate(names)} if names else None
+                model.backward(ctx, gd, grgb, g_aux, gslice)
+
+        if self.density_penalty is not None:  # train.py:153-163
+            gsl = self._slices(grad_flat) if want_grad else (None, None, None)
+            for prefix, model, pflat, gslice in (("fine", self.fine, f_flat, gsl[1]),
+                                                 ("coarse", self.coarse, c_flat, gsl[0])):
+                loss_dict[f"{prefix}_density"] = self._average_density(density_key, model, pflat, bmin, bmax,
+                                                                       gslice if want_grad else None)
+        return loss_dict, world
+
+    def _average_density(self, key, model, pflat, bmin, bmax, gslice):
+        """TrainLoop.average_density (train.py:167-184): mean density at random bbox points."""
+        b = self.density_penalty_batch_size
+        k = as_key(key)
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed((k.seed if isinstance(k, Key) else 0) & 0x7FFFFFFFFFFFFFFF)
+        lo = torch.tensor(bmin, dtype=F32, device=self.device)
+        hi = torch.tensor(bmax, dtype=F32, device=self.device)
+        coords = torch.rand((b, 3), generator=gen, device=self.device) * (hi - lo) + lo
+        dirs = torch.randn((b, 3), generator=gen, device=self.device)
+        dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        dens, rgb, aux, ctx = model.forward_points(pflat, coords.contiguous(), dirs.contiguous(),
+                                                   save=gslice is not None)
+        if gslice is not None:
+            g_d = torch.full_like(dens, self.density_penalty / b)
+            g_aux = {kk: torch.zeros_like(v) for kk, v in aux.items()} if aux else None
+            model.backward(ctx, g_d, torch.zeros_like(rgb), g_aux, gslice)
+        return dens.mean()
+
+    def _step(self, key, bmin, bmax, batch):
+        self.grad.zero_()
+        loss_dict, world = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
+        dist = _dist()
+        if dist and world > 1:
+            with _prof.section("allreduce"):
+                dist.all_reduce(self.grad)  # RCCL sum over ranks; averaged by grad_scale below
+        scale = 1.0 / world
+        with _prof.section("norms_adam"):
+            norms = torch.zeros(2, dtype=F32, device=self.device)
+            ops.sq_norm_into(self.grad, norms[0:1])
+            ops.sq_norm_into(self.flat, norms[1:2])
+            self.state.step += 1
+            ops.adam_step_(self.flat, self.grad, self.state.opt_m, self.state.opt_v, self.lr, self.adam_b1,
+                           self.adam_b2, self.adam_eps, self.state.step, grad_scale=scale)
+            self._params_changed()
+        loss_dict["grad_norm"] = torch.sqrt(norms[0]) * scale  # train.py:99-104
+        loss_dict["param_norm"] = torch.sqrt(norms[1])
+        return loss_dict
+
+    def losses(self, key: KeyLike, bbox_min, bbox_max, batch: torch.Tensor, params=None):
+        """
+        Compute losses and a logging dict for a given batch (train.py:114-165), no gradient.
+        Returns (total_loss, loss_dict) like the reference.
+        """
+        flat = self.flat if params is None else self._flat_from_params(params)
+        loss_dict, _ = self._forward_backward(key, _vec3(bbox_min), _vec3(bbox_max), batch.contiguous(), flat,
+                                              None, False)
+        total = loss_dict["coarse"] + loss_dict["fine"]
+        for k, v in loss_dict.items():
+            for prefix in ("coarse_", "fine_"):
+                if k.startswith(prefix):
+                    name = k[len(prefix):]
+                    if name in self.loss_weights:
+                        total = total + self.loss_weights[name] * v
+                    elif name == "density" and self.density_penalty is not None:
+                        total = total + self.density_penalty * v
+        return total, loss_dict
+
+    def _flat_from_params(self, params) -> torch.Tensor:
+        if params is self.state.params:
+            return self.flat
+        return torch.cat([self.coarse.flat(params["coarse"]).reshape(-1), self.fine.flat(params["fine"]).reshape(-1),
+                          torch.as_tensor(params["background"], dtype=F32, device=self.device).reshape(-1)])
+
+    def average_density(self, key, model, params, bbox_min, bbox_max) -> torch.Tensor:
+        return self._average_density(key, model, model.flat(params), _vec3(bbox_min), _vec3(bbox_max), None)
+
+
+def _tree_to_host(tree):
+    if isinstance(tree, torch.Tensor):
+        return tree.detach().cpu().numpy()
+    return {k: _tree_to_host(v) for k, v in tree.items()}
+
+
+def _tree_from_host(tree, model: ModelBase) -> torch.Tensor:
+    from .params import leaves_in_order
+
+    leaves = leaves_in_order(tree, model.param_spec())
+    return torch.cat([torch.as_tensor(l, dtype=F32).reshape(-1) for l in leaves])
+
+
+def default_loss_weights() -> Dict[str, float]:
+    return dict(normal_mse=3e-4, neg_normal=0.1)  # train.py:187-191
