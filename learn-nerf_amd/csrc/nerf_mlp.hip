@@ -495,36 +495,53 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* frag_even, int lane, int p
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// global -> VGPR -> LDS staging of one 32-evaluation step (NXF + NYF fragments, 8 waves).
-// Buffer B holds the step that goes to LDS slot B.
+// global -> VGPR -> LDS staging of one iteration = SPI consecutive 32-evaluation steps
+// (NXF + NYF fragments each, 8 waves).  The registers hold the iteration that is written to LDS
+// after the next barrier; its loads were issued one whole iteration earlier.
+constexpr int kWgSpi = 2;  // steps per iteration (per barrier)
 template <int NXF, int NYF>
 struct WgStage {
   static constexpr int NF = NXF + NYF;
   static constexpr int PER_WAVE = (NF + kWaves - 1) / kWaves;
   static constexpr int STEP_BYTES = NF * kFragBytes;
+  static constexpr int ITER_BYTES = kWgSpi * STEP_BYTES;
   const char* x_src;  // slot x_slot0, first tile of this K-slice, + lane*16
   const char* y_src;
   int64_t slot_stride;  // bytes between consecutive slots (= n_tiles KiB)
+  int64_t steps;        // steps in this K-slice
   int wave, lane;
-  uint4 rr[2][PER_WAVE];
+  uint4 rr[kWgSpi][PER_WAVE];
 
-  template <int B>
-  __device__ __forceinline__ void load(int64_t step) {
+  // fragment q of this wave is f = wave + 8q; when NF is not a multiple of 8 the surplus waves of
+  // the last round re-load fragment NF-1 (harmless duplicate, keeps the loop branch-free).
+  // Steps past the end of the K-slice are staged as zeros (they contribute nothing).
+  __device__ __forceinline__ void load(int64_t iter) {
 #pragma unroll
-    for (int q = 0; q < PER_WAVE; ++q) {
-      const int f = wave + kWaves * q;
-      if (f < NF) {
+    for (int u = 0; u < kWgSpi; ++u) {
+      const int64_t step = iter * kWgSpi + u;
+      const bool ok = step < steps;
+      const int64_t st = ok ? step : 0;
+      const unsigned keep = ok ? 0xFFFFFFFFu : 0u;  // branch-free zeroing of out-of-range steps
+#pragma unroll
+      for (int q = 0; q < PER_WAVE; ++q) {
+        int f = wave + kWaves * q;
+        if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
         const char* src = f < NXF ? x_src + (int64_t)f * slot_stride : y_src + (int64_t)(f - NXF) * slot_stride;
-        rr[B][q] = *reinterpret_cast<const uint4*>(src + step * kFragBytes);
+        const uint4 v = *reinterpret_cast<const uint4*>(src + st * kFragBytes);
+        rr[u][q] = make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
       }
     }
   }
   template <int B>
   __device__ __forceinline__ void write() {
 #pragma unroll
-    for (int q = 0; q < PER_WAVE; ++q) {
-      const int f = wave + kWaves * q;
-      if (f < NF) *reinterpret_cast<uint4*>(&smem[B * STEP_BYTES + f * kFragBytes + lane * 16]) = rr[B][q];
+    for (int u = 0; u < kWgSpi; ++u) {
+#pragma unroll
+      for (int q = 0; q < PER_WAVE; ++q) {
+        int f = wave + kWaves * q;
+        if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
+        *reinterpret_cast<uint4*>(&smem[B * ITER_BYTES + u * STEP_BYTES + f * kFragBytes + lane * 16]) = rr[u][q];
+      }
     }
   }
 };
@@ -535,9 +552,8 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
                                                               int64_t n_tiles, float* __restrict__ grads) {
   constexpr int NI = NXF / 2, NO = NYF / 2;
   constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;  // tiles per wave
-  constexpr int NF = NXF + NYF;
-  constexpr int STEP_BYTES = NF * kFragBytes;
-  constexpr int PER_WAVE = (NF + kWaves - 1) / kWaves;
+  constexpr bool FULL_I = TI * WI == NI, FULL_O = TO * WO == NO;   // every wave owns TI x TO real tiles
+  using Stage = WgStage<NXF, NYF>;
   static_assert(WI * WO == kWaves, "wave grid");
   static_assert(NXF % 2 == 0 && NYF % 2 == 0, "fragment pairs");
 
@@ -556,11 +572,13 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
   const int64_t t0 = (int64_t)split * per;
   const int64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
   const int64_t steps = t1 > t0 ? t1 - t0 : 0;
+  const int64_t iters = (steps + kWgSpi - 1) / kWgSpi;
 
-  WgStage<NXF, NYF> stg;
+  Stage stg;
   stg.x_src = save + ((int64_t)pb.x_slot0 * n_tiles + t0) * kFragBytes + lane * 16;
   stg.y_src = gdump + ((int64_t)pb.y_slot0 * n_tiles + t0) * kFragBytes + lane * 16;
   stg.slot_stride = n_tiles * kFragBytes;
+  stg.steps = steps;
   stg.wave = wave;
   stg.lane = lane;
 
@@ -572,33 +590,38 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
   float bsum[TO];
 #pragma unroll
   for (int b = 0; b < TO; ++b) bsum[b] = 0.0f;
+  const int ypar = pb.y_slot0 & 1, xpar = pb.x_slot0 & 1;  // slot parity of even fragments
 
-  auto compute = [&](auto slot_) {
-    constexpr int slot = decltype(slot_)::value;
-    const char* buf = smem + slot * STEP_BYTES;
+  auto compute = [&](auto buf_) {
+    constexpr int bufi = decltype(buf_)::value;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      bf16x8 bf[TO];
+    for (int u = 0; u < kWgSpi; ++u) {
+      const char* buf = smem + bufi * Stage::ITER_BYTES + u * Stage::STEP_BYTES;
 #pragma unroll
-      for (int b = 0; b < TO; ++b) {
-        const int ot = wo + WO * b;
-        if (ot < NO) {
-          bf[b] = tr_frag(buf + (NXF + 2 * ot) * kFragBytes, lane, (pb.y_slot0 + 2 * ot) & 1, q);
-          if (wi == 0) {
+      for (int q = 0; q < 2; ++q) {
+        bf16x8 bf[TO];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum[b] += (float)bf[b][j];
+        for (int b = 0; b < TO; ++b) {
+          const int ot = wo + WO * b;
+          if (FULL_O || ot < NO) {
+            bf[b] = tr_frag(buf + (NXF + 2 * ot) * kFragBytes, lane, ypar, q);
+            if (wi == 0) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) bsum[b] += (float)bf[b][j];
+            }
           }
         }
-      }
 #pragma unroll
-      for (int a = 0; a < TI; ++a) {
-        const int it = wi + WI * a;
-        if (it < NI) {
-          const bf16x8 af = tr_frag(buf + 2 * it * kFragBytes, lane, (pb.x_slot0 + 2 * it) & 1, q);
+        for (int a = 0; a < TI; ++a) {
+          const int it = wi + WI * a;
+          if (FULL_I || it < NI) {
+            const bf16x8 af = tr_frag(buf + 2 * it * kFragBytes, lane, xpar, q);
 #pragma unroll
-          for (int b = 0; b < TO; ++b) {
-            const int ot = wo + WO * b;
-            if (ot < NO) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < TO; ++b) {
+              const int ot = wo + WO * b;
+              if (FULL_O || ot < NO)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[b], acc[a][b], 0, 0, 0);
+            }
           }
         }
       }
@@ -606,22 +629,22 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
   };
   std::integral_constant<int, 0> c0;
   std::integral_constant<int, 1> c1;
-  // software pipeline: loads of steps s+2, s+3 are in registers while step s is consumed
-  if (steps > 0) stg.template load<0>(0);
-  if (steps > 1) stg.template load<1>(1);
-  if (steps > 0) stg.template write<0>();
-  if (steps > 2) stg.template load<0>(2);
-  for (int64_t s = 0; s < steps; s += 2) {
+  // iteration i: barrier | write iteration i+1 (registers) to LDS buffer (i+1)&1 | load iteration i+2 |
+  // compute iteration i from buffer i&1.  Loads stay in flight for one whole iteration of MFMA work.
+  if (iters > 0) {
+    stg.load(0);
+    stg.template write<0>();
+    stg.load(1);
+  }
+  for (int64_t i = 0; i < iters; i += 2) {
     __syncthreads();
-    if (s + 1 < steps) stg.template write<1>();
-    if (s + 3 < steps) stg.template load<1>(s + 3);
+    stg.template write<1>();
+    stg.load(i + 2);
     compute(c0);
-    if (s + 1 < steps) {
-      __syncthreads();
-      if (s + 2 < steps) stg.template write<0>();
-      if (s + 4 < steps) stg.template load<0>(s + 4);
-      compute(c1);
-    }
+    __syncthreads();
+    stg.template write<0>();
+    stg.load(i + 3);
+    if (i + 1 < iters) compute(c1);
   }
 
   // epilogue: atomically add the partial dW tiles / bias sums
@@ -857,7 +880,7 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
 #define LAUNCH_WGRAD(NXF, NYF, WI, WO, ARGS, BLOCKS_EACH)                                              \
   do {                                                                                                 \
     const int grid_ = finish(ARGS, BLOCKS_EACH);                                                       \
-    const int lds_ = 2 * ((NXF) + (NYF)) * kFragBytes;                                                 \
+    const int lds_ = 2 * kWgSpi * ((NXF) + (NYF)) * kFragBytes;                                                 \
     rc = ensure_lds(nerf_wgrad_kernel<NXF, NYF, WI, WO>, lds_);                                        \
     if (rc) return rc;                                                                                 \
     hipLaunchKernelGGL((nerf_wgrad_kernel<NXF, NYF, WI, WO>), dim3((unsigned)grid_), dim3(kThreads), lds_, \
