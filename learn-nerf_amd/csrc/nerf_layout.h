@@ -188,7 +188,10 @@ constexpr int kSaveDin = 4;    // 2 slots
 constexpr int kSaveH = 6;      // h0..h7 (relu outputs of Dense_0..7): 16 slots each
 constexpr int kSaveZ = 6 + 8 * 16;      // z = Dense_8 output (linear): 16 slots
 constexpr int kSaveH10 = kSaveZ + 16;   // relu(Dense_10): 8 slots
-constexpr int kSaveSlots = kSaveH10 + 8;  // 158
+constexpr int kSaveMask = kSaveH10 + 8;   // ReLU masks, one 1 KiB slot per layer: h0..h7, h10 (9 slots);
+                                          // lane l keeps a uint4 at l*16: bit 16*o + q of the 128 = acc reg q
+                                          // of out-tile o was > 0
+constexpr int kSaveSlots = kSaveMask + 9;  // 167
 // backward dump slots (pre-activation gradients)
 constexpr int kGradDy11 = 0;            // 2 slots (second is zero padding)
 constexpr int kGradDy10m = 2;           // 10 slots: 8 for Dense_10 outputs, slot 8 = logit, slot 9 zero

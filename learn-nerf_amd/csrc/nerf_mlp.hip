@@ -124,9 +124,31 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& acc) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float v = acc[8 * S + j];
-    if (RELU) v = fmaxf(v, 0.0f);
+    if (RELU) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());  // max(v, 0) in one VALU op
     f[j] = (__bf16)v;
   }
+  return f;
+}
+
+// ReLU mask of one out-tile from its two bf16 output fragments: bit 8s + j set <=> element j of
+// fragment s is non-zero (ReLU output > 0), i.e. accumulator register 8s + j passed the ReLU
+__device__ __forceinline__ unsigned relu_bits(const bf16x8& f0, const bf16x8& f1) {
+  const uint4 a = frag_to_bits(f0), b = frag_to_bits(f1);
+  const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned bits = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    bits |= ((w[i] & 0xFFFFu) != 0u ? 1u : 0u) << (2 * i);
+    bits |= ((w[i] >> 16) != 0u ? 1u : 0u) << (2 * i + 1);
+  }
+  return bits;
+}
+// dy = dh * mask: registers 8s..8s+7 of the tile whose 16 mask bits start at bit `shift` of `bits`
+template <int S>
+__device__ __forceinline__ bf16x8 masked_frag(const f32x16& acc, unsigned bits, int shift) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (__bf16)(((bits >> (shift + 8 * S + j)) & 1u) ? acc[8 * S + j] : 0.0f);
   return f;
 }
 
@@ -254,6 +276,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   }
 
   bf16x8 a0[16], a1[16];
+  unsigned mask_bits[4] = {0u, 0u, 0u, 0u};
 
   // hidden layer: in (16 k-steps, + optional 4 extra), out 256 features
   auto hidden = [&](auto s_, bf16x8(&in)[16], bf16x8(&out)[16], auto relu_, int save_slot) {
@@ -273,7 +296,14 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           out[2 * o + 1] = acc_to_frag<1, RELU>(acc);
           save_frag(save_slot + 2 * o, out[2 * o]);
           save_frag(save_slot + 2 * o + 1, out[2 * o + 1]);
+          if constexpr (SAVE && RELU) mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
         });
+    if constexpr (SAVE && RELU) {
+      if (tile_ok)
+        *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile) * kFragBytes + lane * 16) =
+            make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
+      mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
+    }
   };
   std::true_type relu;
   std::false_type lin;
@@ -302,7 +332,13 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           a1[2 * o + 1] = acc_to_frag<1, true>(acc);
           save_frag(kSaveH10 + 2 * o, a1[2 * o]);
           save_frag(kSaveH10 + 2 * o + 1, a1[2 * o + 1]);
+          if constexpr (SAVE) mask_bits[o >> 1] |= relu_bits(a1[2 * o], a1[2 * o + 1]) << (16 * (o & 1));
         } else {
+          if constexpr (SAVE) {
+            if (tile_ok)
+              *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + 8) * n_tiles + tile) * kFragBytes +
+                                        lane * 16) = make_uint4(mask_bits[0], mask_bits[1], 0u, 0u);
+          }
           if (h == 0 && valid) {
             const float x = acc[0];
             density[m] = fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));  // softplus (model.py:57)
@@ -327,18 +363,6 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int kBwdStages = kBwdFrags / kStageFrags;  // 70
 
-__device__ __forceinline__ bf16x8 mask_frag(const f32x16& acc, int s, uint4 saved_bits) {
-  // dy = dh * [h > 0] where h is the saved relu output (bf16, same fragment slot)
-  const bf16x8 hsv = bits_to_frag(saved_bits);
-  bf16x8 f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = s == 0 ? acc[j] : acc[8 + j];
-    f[j] = (__bf16)(((float)hsv[j] > 0.0f) ? v : 0.0f);
-  }
-  return f;
-}
-
 __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
     const char* __restrict__ packed, const char* __restrict__ save, const float* __restrict__ density,
     const float* __restrict__ rgb, const float* __restrict__ g_density, const float* __restrict__ g_rgb,
@@ -362,6 +386,13 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
     }
     gy9 = g_density[m] * (1.0f - expf(-density[m]));           // softplus' = sigmoid = 1 - exp(-sp)
   }
+  // ReLU masks of h0..h7 and h10 (written by the forward), 16 bytes per lane and layer
+  uint4 relu_mask[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    relu_mask[i] = tile_ok ? *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) *
+                                                                        kFragBytes + lane * 16)
+                           : make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   Ring<kBwdStages> ring;
@@ -370,11 +401,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   ring.lane = lane;
   ring.prologue();
 
-  DumpAddr sv{const_cast<char*>(save), n_tiles, tile, c, h};
   DumpAddr gd{gdump, n_tiles, tile, c, h};
-  auto load_saved = [&](int slot) -> uint4 {
-    return tile_ok ? *reinterpret_cast<const uint4*>(sv.at(slot)) : make_uint4(0, 0, 0, 0);
-  };
   auto dump_frag = [&](int slot, const bf16x8& f) {
     if (tile_ok) *reinterpret_cast<uint4*>(gd.at(slot)) = frag_to_bits(f);
   };
@@ -394,8 +421,9 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
       ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy11; },
       [&](auto o_, const f32x16& acc) {
         constexpr int o = decltype(o_)::value;
-        a0[2 * o] = mask_frag(acc, 0, load_saved(kSaveH10 + 2 * o));
-        a0[2 * o + 1] = mask_frag(acc, 1, load_saved(kSaveH10 + 2 * o + 1));
+        const unsigned mb = (o >> 1) == 0 ? relu_mask[8].x : relu_mask[8].y;
+        a0[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
+        a0[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
         dump_frag(kGradDy10m + 2 * o, a0[2 * o]);
         dump_frag(kGradDy10m + 2 * o + 1, a0[2 * o + 1]);
       });
@@ -430,8 +458,10 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
         [&](auto k_) -> bf16x8 { return in[decltype(k_)::value]; },
         [&](auto o_, const f32x16& acc) {
           constexpr int o = decltype(o_)::value;
-          out[2 * o] = mask_frag(acc, 0, load_saved(kSaveH + (l - 1) * 16 + 2 * o));
-          out[2 * o + 1] = mask_frag(acc, 1, load_saved(kSaveH + (l - 1) * 16 + 2 * o + 1));
+          const uint4 mk = relu_mask[l - 1];
+          const unsigned mb = (o >> 1) == 0 ? mk.x : ((o >> 1) == 1 ? mk.y : ((o >> 1) == 2 ? mk.z : mk.w));
+          out[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
+          out[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
           dump_frag(grad_dy_slot(l - 1) + 2 * o, out[2 * o]);
           dump_frag(grad_dy_slot(l - 1) + 2 * o + 1, out[2 * o + 1]);
         });
@@ -457,6 +487,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
 enum { ROW_HIDDEN = 0, ROW_XEMB = 1, ROW_DEMB = 2 };
 enum { COL_256 = 0, COL_DY10M = 1, COL_DY11 = 2 };
 struct WgradProblem {
+  int shape;     // operand-shape body, see nerf_wgrad_kernel
   int x_slot0;   // first X slot in the forward save buffer
   int y_slot0;   // first dy slot in the gradient dump
   int dense;     // Flax Dense index (COL_DY10M: Dense_10 with Dense_9 attached as column 128)
@@ -466,7 +497,7 @@ struct WgradProblem {
   int do_bias;
   int first_block, n_blocks;
 };
-constexpr int kMaxProblems = 8;
+constexpr int kMaxProblems = 13;
 struct WgradArgs {
   WgradProblem p[kMaxProblems];
   int n_problems;
@@ -498,9 +529,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* frag_even, int lane, int p
 // global -> VGPR -> LDS staging of one iteration = SPI consecutive 32-evaluation steps
 // (NXF + NYF fragments each, 8 waves).  The registers hold the iteration that is written to LDS
 // after the next barrier; its loads were issued one whole iteration earlier.
-constexpr int kWgSpi = 2;  // steps per iteration (per barrier)
-template <int NXF, int NYF>
+template <int NXF, int NYF, int SPI>  // SPI = steps per iteration (per barrier)
 struct WgStage {
+  static constexpr int kWgSpi = SPI;
   static constexpr int NF = NXF + NYF;
   static constexpr int PER_WAVE = (NF + kWaves - 1) / kWaves;
   static constexpr int STEP_BYTES = NF * kFragBytes;
@@ -546,21 +577,18 @@ struct WgStage {
   }
 };
 
-template <int NXF, int NYF, int WI, int WO>
-__global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, const char* __restrict__ save,
-                                                              const char* __restrict__ gdump,
-                                                              int64_t n_tiles, float* __restrict__ grads) {
+template <int NXF, int NYF, int WI, int WO, int SPI>
+__device__ __forceinline__ void wgrad_body(const WgradProblem& pb, const char* __restrict__ save,
+                                           const char* __restrict__ gdump, int64_t n_tiles,
+                                           float* __restrict__ grads) {
   constexpr int NI = NXF / 2, NO = NYF / 2;
   constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;  // tiles per wave
   constexpr bool FULL_I = TI * WI == NI, FULL_O = TO * WO == NO;   // every wave owns TI x TO real tiles
-  using Stage = WgStage<NXF, NYF>;
+  using Stage = WgStage<NXF, NYF, SPI>;
+  constexpr int kWgSpi = SPI;
   static_assert(WI * WO == kWaves, "wave grid");
   static_assert(NXF % 2 == 0 && NYF % 2 == 0, "fragment pairs");
 
-  WgradProblem pb = args.p[0];
-#pragma unroll
-  for (int i = 1; i < kMaxProblems; ++i)
-    if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
   const int split = blockIdx.x - pb.first_block;
 
   const int tid = threadIdx.x;
@@ -687,6 +715,25 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
       });
     });
   });
+}
+
+// One launch for every Dense layer of the model: blockIdx -> problem -> operand-shape body.
+// Problems are listed heaviest first so that the small ones fill the tail of the launch.
+__global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, const char* __restrict__ save,
+                                                              const char* __restrict__ gdump,
+                                                              int64_t n_tiles, float* __restrict__ grads) {
+  WgradProblem pb = args.p[0];
+#pragma unroll
+  for (int i = 1; i < kMaxProblems; ++i)
+    if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
+  switch (pb.shape) {
+    // steps per barrier chosen so that every body keeps ~60 KB of loads in flight per workgroup
+    case 0: wgrad_body<16, 16, 4, 2, 2>(pb, save, gdump, n_tiles, grads); break;
+    case 1: wgrad_body<16, 10, 4, 2, 2>(pb, save, gdump, n_tiles, grads); break;
+    case 2: wgrad_body<4, 16, 2, 4, 3>(pb, save, gdump, n_tiles, grads); break;
+    case 3: wgrad_body<2, 10, 1, 8, 5>(pb, save, gdump, n_tiles, grads); break;
+    default: wgrad_body<8, 2, 4, 2, 6>(pb, save, gdump, n_tiles, grads); break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -859,66 +906,39 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   const int64_t n_tiles = tiles_for(m);
   hipStream_t st = as_stream(stream);
   int rc;
-  // weight-gradient problems, one launch per operand shape
-  auto mk = [&](int xs, int ys, int dense, int row_map, int row_off, int col_map, int do_bias) {
+  // weight-gradient problems: ONE launch, heaviest problems first
+  WgradArgs a;
+  a.n_problems = 0;
+  int first = 0;
+  auto add = [&](int shape, int xs, int ys, int dense, int row_map, int row_off, int col_map, int do_bias,
+                 int blocks) {
     WgradProblem p;
-    p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
-    p.col_map = col_map; p.do_bias = do_bias; p.first_block = 0; p.n_blocks = 0;
-    return p;
+    p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
+    p.col_map = col_map; p.do_bias = do_bias;
+    int64_t nb = blocks;
+    const int64_t max_nb = (n_tiles + 5) / 6;
+    if (nb > max_nb) nb = max_nb;
+    p.first_block = first;
+    p.n_blocks = (int)nb;
+    first += (int)nb;
+    a.p[a.n_problems++] = p;
   };
-  auto finish = [&](WgradArgs& a, int blocks_each) -> int {
-    int first = 0;
-    for (int i = 0; i < a.n_problems; ++i) {
-      int64_t nb = blocks_each;
-      if (nb > n_tiles) nb = n_tiles;
-      a.p[i].first_block = first;
-      a.p[i].n_blocks = (int)nb;
-      first += (int)nb;
-    }
-    return first;
-  };
-#define LAUNCH_WGRAD(NXF, NYF, WI, WO, ARGS, BLOCKS_EACH)                                              \
-  do {                                                                                                 \
-    const int grid_ = finish(ARGS, BLOCKS_EACH);                                                       \
-    const int lds_ = 2 * kWgSpi * ((NXF) + (NYF)) * kFragBytes;                                                 \
-    rc = ensure_lds(nerf_wgrad_kernel<NXF, NYF, WI, WO>, lds_);                                        \
-    if (rc) return rc;                                                                                 \
-    hipLaunchKernelGGL((nerf_wgrad_kernel<NXF, NYF, WI, WO>), dim3((unsigned)grid_), dim3(kThreads), lds_, \
-                       st, ARGS, (const char*)save, (const char*)scratch, n_tiles, grads);             \
-    LNRF_LAUNCH_CHECK();                                                                               \
-  } while (0)
-  {
-    WgradArgs a;  // hidden x hidden: Dense_1..8 (Dense_5: rows 0..255)
-    a.n_problems = 0;
-    for (int l = 1; l <= 8; ++l)
-      a.p[a.n_problems++] = mk(kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, COL_256, 1);
-    LAUNCH_WGRAD(16, 16, 4, 2, a, 64);
-  }
-  {
-    WgradArgs a;  // x_emb x dy0 (Dense_0) and x_emb x dy5 (Dense_5 rows 256..315)
-    a.n_problems = 0;
-    a.p[a.n_problems++] = mk(kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_256, 1);
-    a.p[a.n_problems++] = mk(kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, COL_256, 0);
-    LAUNCH_WGRAD(4, 16, 2, 4, a, 128);
-  }
-  {
-    WgradArgs a;  // z x dy10m: Dense_10 rows 0..255 and Dense_9
-    a.n_problems = 0;
-    a.p[a.n_problems++] = mk(kSaveZ, kGradDy10m, 10, ROW_HIDDEN, 0, COL_DY10M, 1);
-    LAUNCH_WGRAD(16, 10, 4, 2, a, 256);
-  }
-  {
-    WgradArgs a;  // d_emb x dy10m: Dense_10 rows 256..279
-    a.n_problems = 0;
-    a.p[a.n_problems++] = mk(kSaveDin, kGradDy10m, 10, ROW_DEMB, 256, COL_DY10M, 0);
-    LAUNCH_WGRAD(2, 10, 1, 8, a, 256);
-  }
-  {
-    WgradArgs a;  // h10 x dy11: Dense_11
-    a.n_problems = 0;
-    a.p[a.n_problems++] = mk(kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);
-    LAUNCH_WGRAD(8, 2, 4, 2, a, 256);
-  }
-#undef LAUNCH_WGRAD
+  // hidden x hidden: Dense_1..8 (Dense_5: rows 0..255)
+  for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, COL_256, 1, l <= 4 ? 48 : 47);
+  // z x dy10m: Dense_10 rows 0..255 and Dense_9
+  add(1, kSaveZ, kGradDy10m, 10, ROW_HIDDEN, 0, COL_DY10M, 1, 39);
+  // x_emb x dy0 (Dense_0) and x_emb x dy5 (Dense_5 rows 256..315)
+  add(2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_256, 1, 30);
+  add(2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, COL_256, 0, 30);
+  // d_emb x dy10m: Dense_10 rows 256..279
+  add(3, kSaveDin, kGradDy10m, 10, ROW_DEMB, 256, COL_DY10M, 0, 18);
+  // h10 x dy11: Dense_11
+  add(4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1, 15);
+  const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
+  rc = ensure_lds(nerf_wgrad_kernel, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)first), dim3(kThreads), lds, st, a, (const char*)save,
+                     (const char*)scratch, n_tiles, grads);
+  LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
