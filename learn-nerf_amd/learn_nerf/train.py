@@ -19,6 +19,7 @@ import torch
 
 from . import _prof
 from . import ops
+from . import parallel
 from .model import ModelBase
 from .params import ParamTree, as_generator, build_tree, default_device, split_seed
 from .render import STREAM_COARSE, STREAM_FINE, NeRFRenderer, _vec3
@@ -217,10 +218,9 @@ class TrainLoop:
     def _step(self, key, bmin, bmax, batch):
         self.grad.zero_()
         loss_dict, world = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
-        dist = _dist()
-        if dist and world > 1:
+        if world > 1:
             with _prof.section("allreduce"):
-                dist.all_reduce(self.grad)  # RCCL sum over ranks; averaged by grad_scale below
+                parallel.all_reduce_sum_(self.grad)  # RCCL sum over ranks; averaged by grad_scale below
         scale = 1.0 / world
         with _prof.section("norms_adam"):
             norms = torch.zeros(2, dtype=F32, device=self.device)

@@ -1,0 +1,177 @@
+"""
+CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/lnrf.h declares,
+the ctypes prototypes cover the header, host-side logic (parameter trees, keys, dataset format,
+camera rays) behaves like the reference, and the product path refuses to run without a GPU.
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lnrf.h")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lnrf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    from learn_nerf import _lib
+
+    lib = _lib.lib()  # raises if the .so is missing: build() must have run
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for name in syms:
+        assert hasattr(lib, name), f"liblnrf.so does not export {name}"
+        assert name in _lib.PROTOTYPES, f"no ctypes prototype for {name}"
+    assert set(_lib.PROTOTYPES) == set(syms), "prototype table and header disagree"
+    assert lib.lnrf_version() == 100
+
+
+def test_size_queries_without_gpu():
+    import ctypes
+
+    from learn_nerf import _lib
+
+    lib = _lib.lib()
+    shape = _lib.NerfShape(5, 4, 256, 128, 10, 4)
+    assert lib.lnrf_nerf_param_count(ctypes.byref(shape)) == 593_924
+    assert lib.lnrf_nerf_packed_bytes(ctypes.byref(shape)) == (1200 + 1120) * 1024 + 10240
+    assert lib.lnrf_nerf_save_bytes(ctypes.byref(shape), 4096 * 192) == 167 * 24576 * 1024
+    assert lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), 33) == 156 * 2 * 1024
+    other = _lib.NerfShape(5, 4, 128, 128, 10, 4)
+    assert lib.lnrf_nerf_param_count(ctypes.byref(other)) > 0
+    assert lib.lnrf_nerf_packed_bytes(ctypes.byref(other)) == -1  # fused path: default shape only
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from learn_nerf import ops
+    from learn_nerf.model import NeRFModel
+
+    with pytest.raises(RuntimeError, match="GPU"):
+        NeRFModel().init(dict(params=0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.ray_aabb_stratified(torch.zeros(4, 2, 3), (-1, -1, -1), (1, 1, 1), 4)
+
+
+def test_param_tree_views_and_spec():
+    from learn_nerf.model import NeRFModel
+    from learn_nerf.params import build_tree, flat_of
+
+    m = NeRFModel()
+    spec = m.param_spec()
+    assert [s[0] for s in spec[:2]] == ["Dense_0", "Dense_0"] and spec[0][2] == (60, 256)
+    assert m.num_params() == 593_924
+    flat = torch.arange(m.num_params(), dtype=torch.float32)
+    tree = build_tree(flat, spec)
+    assert tree["Dense_5"]["kernel"].shape == (316, 256) and tree["Dense_11"]["bias"].shape == (3,)
+    tree["Dense_0"]["bias"][0] = -5.0  # a view: writes go to the flat buffer
+    assert flat[60 * 256] == -5.0
+    assert flat_of(tree, spec) is flat
+    plain = {k: dict(v) for k, v in tree.items()}  # e.g. a tree restored from a checkpoint
+    assert torch.equal(flat_of(plain, spec), flat)
+    gen = torch.Generator().manual_seed(0)
+    f2 = torch.zeros(m.num_params())
+    m.init_flat_(f2, gen)
+    t2 = build_tree(f2, spec)
+    k0 = t2["Dense_0"]["kernel"]
+    assert abs(k0.std().item() - (1 / 60) ** 0.5) < 0.01  # lecun_normal: var = 1/fan_in
+    assert k0.abs().max().item() <= 2.0 / 0.87962566 * (1 / 60) ** 0.5 + 1e-6  # truncated at 2 sigma
+    assert (t2["Dense_3"]["bias"] == 0).all()
+
+
+def test_key_split_is_deterministic():
+    from learn_nerf.rng import Key, Uniforms, sampler_args, split
+
+    a, b = split(Key(5), 2)
+    a2, b2 = split(5, 2)
+    assert (a, b) == (a2, b2) and a.seed != b.seed
+    assert Key(5, ray_offset=7).split(2)[0].ray_offset == 7
+    u = Uniforms(torch.zeros(2, 3))
+    assert sampler_args(u, 0)["u"] is not None and sampler_args(a, 1)["seed"] == a.seed
+    with pytest.raises(TypeError):
+        split(u, 2)
+
+
+def _views():
+    from learn_nerf.dataset import NeRFView
+
+    class DummyView(NeRFView):
+        def __init__(self, img, **kw):
+            super().__init__(**kw)
+            self._img = img
+
+        def image(self):
+            return self._img
+
+    rng = np.random.default_rng(0)
+    v1 = DummyView((rng.random((10, 10, 3)) * 255).astype(np.uint8), camera_direction=(0.0, 1.0, 0.0),
+                   camera_origin=(2.0, 2.0, 2.0), x_axis=(-1.0, 0.0, 0.0), y_axis=(0.0, 0.0, 1.0), x_fov=1.0,
+                   y_fov=1.0)
+    v2 = DummyView((rng.random((10, 10, 3)) * 255).astype(np.uint8), camera_direction=(1.0, 0.0, 0.0),
+                   camera_origin=(-2.0, 2.0, 2.0), x_axis=(0.0, 0.0, -1.0), y_axis=(0.0, 1.0, 0.0), x_fov=1.0,
+                   y_fov=1.0)
+    return [v1, v2]
+
+
+def test_dataset_iterate_batches_invariants(tmp_path):
+    """The invariants of the reference's only test (learn_nerf/test_dataset.py:49-81)."""
+    from learn_nerf.dataset import ModelMetadata, NeRFDataset
+
+    views = _views()
+    ds = NeRFDataset(metadata=ModelMetadata((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), views=views)
+    batches = list(ds.iterate_batches(str(tmp_path / "sh"), 1234, batch_size=51, repeat=False))
+    assert len(batches) == 4 and batches[-1].shape[0] == 200 - 51 * 3
+    combined = torch.cat(batches, 0)
+    assert combined.shape == (200, 3, 3)
+    for v in views:
+        origin = torch.tensor(v.camera_origin)
+        sel = (combined[:, 0] - origin).abs().sum(-1) < 1e-5
+        assert int(sel.sum()) == 100
+        mean_dir = combined[sel][:, 1].mean(0)
+        mean_dir = mean_dir / mean_dir.norm()
+        assert abs(float((mean_dir * torch.tensor(v.camera_direction)).sum()) - 1) < 1e-5
+        mean_col = combined[sel][:, 2].mean(0)
+        actual = torch.from_numpy(v.image().astype(np.float32) / 127.5 - 1).mean((0, 1))
+        assert float((mean_col - actual).abs().mean()) < 1e-5
+    # shards are raw little-endian fp32 [k,3,3] files "0".."31" + "done" (dataset.py:255-263)
+    names = sorted(os.listdir(tmp_path / "sh"))
+    assert "done" in names and len(names) == 33
+    total = sum(os.path.getsize(tmp_path / "sh" / str(i)) for i in range(32))
+    assert total == 200 * 9 * 4
+    # a second iterator re-uses the shards and repeats forever
+    it = ds.iterate_batches(str(tmp_path / "sh"), 1234, batch_size=64, repeat=True)
+    assert all(next(it).shape == (64, 3, 3) for _ in range(7))
+
+
+def test_camera_rays_and_json_roundtrip(tmp_path):
+    from learn_nerf.dataset import CameraView, ModelMetadata
+
+    v = CameraView(camera_direction=(0.0, 0.0, -1.0), camera_origin=(0.0, 0.0, 4.0), x_axis=(1.0, 0.0, 0.0),
+                   y_axis=(0.0, -1.0, 0.0), x_fov=0.6, y_fov=0.6)
+    rays = v.bare_rays(5, 3)
+    assert rays.shape == (15, 2, 3) and rays.dtype == torch.float32
+    assert torch.allclose(rays[:, 1].norm(dim=-1), torch.ones(15), atol=1e-6)
+    centre = rays[7, 1]  # middle pixel looks along the camera direction (dataset.py:59-70)
+    assert torch.allclose(centre, torch.tensor([0.0, 0.0, -1.0]), atol=1e-6)
+    import math
+
+    corner = rays[0, 1]  # row 0, col 0: -x_axis, -y_axis
+    expect = torch.tensor([-math.tan(0.3), math.tan(0.3), -1.0])
+    assert torch.allclose(corner, expect / expect.norm(), atol=1e-6)
+    p = tmp_path / "0000.json"
+    p.write_text(v.to_json())
+    v2 = CameraView.from_json(str(p))
+    assert v2 == v
+    (tmp_path / "metadata.json").write_text(json.dumps({"min": [-1, -1, -1], "max": [1, 1, 1]}))
+    md = ModelMetadata.from_json(str(tmp_path / "metadata.json"))
+    assert md.bbox_min == (-1, -1, -1) and md.bbox_max == (1, 1, 1)
