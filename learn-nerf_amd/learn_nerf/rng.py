@@ -45,7 +45,7 @@ def split(key: KeyLike, n: int = 2):
     """jax.random.split stand-in. A tuple/list of n keys is passed through (explicit per-use keys)."""
     if isinstance(key, (tuple, list)):
         assert len(key) == n
-        return [as_key(k) for k in key]
+        return [k if isinstance(k, (tuple, list)) else as_key(k) for k in key]
     k = as_key(key)
     if isinstance(k, Uniforms):
         raise TypeError("explicit Uniforms cannot be split; pass a tuple of keys")

@@ -110,25 +110,36 @@ class TrainLoop:
 
     # ---- checkpointing (train.py:62-76) ------------------------------------------------------------
     def save(self, path: str):
-        """Save the model parameters to a file (atomic rename, params only, like the reference)."""
+        """
+        Save the model parameters to a file (atomic rename like train.py:62-69).  Besides the reference's
+        params tree {"coarse", "fine", "background"} the file also keeps the Adam moments and step count
+        (the reference drops them, so every resume restarts Adam's bias correction).
+        """
         tmp_path = path + ".tmp"
         c, f, bg = self._slices(self.flat)
-        blob = dict(format="lnrf-params-v1",
+        blob = dict(format="lnrf-params-v2",
                     coarse=_tree_to_host(self.state.params["coarse"]),
                     fine=_tree_to_host(self.state.params["fine"]),
-                    background=bg.detach().cpu().numpy())
+                    background=bg.detach().cpu().numpy(),
+                    opt_state=dict(step=self.state.step, m=self.state.opt_m.detach().cpu().numpy(),
+                                   v=self.state.opt_v.detach().cpu().numpy()))
         with open(tmp_path, "wb") as fh:
             pickle.dump(blob, fh)
         os.rename(tmp_path, path)
 
-    def load(self, path: str):
-        """Load the model parameters from a file written by save()."""
+    def load(self, path: str, load_optimizer: bool = True):
+        """Load parameters (and, when present, the optimiser state) from a file written by save()."""
         with open(path, "rb") as fh:
             blob = pickle.load(fh)
         c, f, bg = self._slices(self.flat)
         c.copy_(_tree_from_host(blob["coarse"], self.coarse).to(self.device))
         f.copy_(_tree_from_host(blob["fine"], self.fine).to(self.device))
         bg.copy_(torch.as_tensor(blob["background"], dtype=F32).to(self.device))
+        opt = blob.get("opt_state")
+        if load_optimizer and opt is not None and opt["m"].shape[0] == self.flat.numel():
+            self.state.opt_m.copy_(torch.as_tensor(opt["m"], dtype=F32).to(self.device))
+            self.state.opt_v.copy_(torch.as_tensor(opt["v"], dtype=F32).to(self.device))
+            self.state.step = int(opt["step"])
         self._params_changed()
 
     # ---- the step --------------------------------------------------------------------------------

@@ -40,7 +40,7 @@ def psnr(img_u8, ref_u8):
     return -10 * np.log10(np.mean(((a - b) / 2) ** 2))
 
 
-@pytest.mark.parametrize("coarse,fine,batch,steps,min_psnr", [(64, 0, 256, 600, 17.0), (32, 64, 1024, 500, 19.0)])
+@pytest.mark.parametrize("coarse,fine,batch,steps,min_psnr", [(64, 0, 256, 600, 22.0), (32, 64, 1024, 500, 26.0)])
 def test_train_resume_render(tmp_path, coarse, fine, batch, steps, min_psnr):
     from PIL import Image
 
@@ -56,11 +56,12 @@ def test_train_resume_render(tmp_path, coarse, fine, batch, steps, min_psnr):
     last = np.mean([r["fine"] for r in rows[-20:]])
     assert last < 0.35 * first, (first, last)
     assert os.path.exists(ckpt) and not os.path.exists(ckpt + ".tmp")
-    # resume: picks the checkpoint up and continues from the trained loss level (train_nerf.py:91-93)
+    # resume: picks the checkpoint up (train_nerf.py:91-93) and, because the Adam state is checkpointed
+    # too, continues at the trained loss level without a bias-correction jolt
     out2 = run([os.path.join(SCRIPTS, "train_nerf.py")] + common + ["--max_steps", "20", data])
     assert "loading from checkpoint" in out2
     rows2 = read_log(out2)
-    assert np.mean([r["fine"] for r in rows2[:10]]) < 0.6 * first
+    assert np.mean([r["fine"] for r in rows2]) < 3 * last + 1e-3
     png = str(tmp_path / "out.png")
     run([os.path.join(SCRIPTS, "render_nerf.py"), "--seed", "0", "--batch_size", "512", "--coarse_samples",
          str(coarse), "--fine_samples", str(fine), "--width", "32", "--height", "32", "--model_path", ckpt,
