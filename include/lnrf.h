@@ -141,9 +141,41 @@ int lnrf_act_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int32_t act
 int lnrf_dense_bwd_input(const float* gy, int64_t ldgy, const float* w, float* gx, int64_t ldgx,
                          int32_t accumulate, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
 
-/* g_w[K,N] += x[M,K]^T @ g_y[M,N];  g_b[N] += sum_m g_y (g_b may be NULL). */
+/* g_w[K,N] += x[M,K]^T @ g_y[M,N];  g_b[N] += sum_m g_y (g_b may be NULL).
+ * x == NULL and gw == NULL: bias gradient only. */
 int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gw,
                           float* gb, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
+
+/* General strided fp32 GEMM on the f32 MFMA behind the dense entry points above:
+ *   C[i*ldc + j] (op)= sum_r A[i*sa_i + r*sa_r] * B[r*sb_r + j*sb_j],  i < I, j < J, r < R
+ * mode 0: C = act(sum + bias[j]);  1: C += sum;  2: atomic C += sum with the reduction split over
+ * `splits` workgroups (0 = choose).  Lets a layer consume a transposed operand (e.g. the feature-major
+ * hash-grid encoding) without a copy. */
+int lnrf_gemm_f32(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r, int64_t sb_j,
+                  float* c, int64_t ldc, const float* bias, int32_t act, int32_t mode, int64_t i_rows,
+                  int32_t j_cols, int64_t r_depth, int32_t splits, lnrf_stream_t stream);
+
+/* --------------------------------------------------- hash-grid encoding ---- */
+
+/* MultiresHashTableEncoding / HashTableEncoding (instant_ngp.py:92-208). Tables of all levels live in one
+ * flat fp32 buffer; level l is [table_size[l], feature_dim] row-major at table_offset[l] (floats). */
+typedef struct {
+  int32_t n_levels, feature_dim, smooth, pad_;
+  float bbox_min[3], bbox_max[3];
+  int32_t grid_size[32];
+  int32_t table_size[32];
+  int64_t table_offset[32];
+  int32_t hashed[32]; /* 1 when grid_size^3 > requested table size (instant_ngp.py:178) */
+} lnrf_hashgrid_desc;
+
+/* enc_t[(level*F + f) * m_total + m] = sum over the 8 cell corners of weight * table[index][f]
+ * (feature-major output, [L*F][M]). x: [M,3] points. */
+int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, int64_t m,
+                      float* enc_t, lnrf_stream_t stream);
+
+/* g_tables += scatter of g_enc_t (same layout as enc_t) through the same indices/weights. */
+int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m, const float* g_enc_t,
+                      float* g_tables, lnrf_stream_t stream);
 
 /* ------------------------------------------------ fused NeRF MLP (bf16 MFMA) ---- */
 

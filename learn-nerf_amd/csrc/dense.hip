@@ -205,16 +205,18 @@ extern "C" int lnrf_dense_bwd_input(const float* gy, int64_t ldgy, const float* 
 extern "C" int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
                                      float* gw, float* gb, int64_t m, int32_t k, int32_t n,
                                      lnrf_stream_t stream) {
-  LNRF_CHECK_ARG(x && gy && gw, "null pointer");
-  LNRF_CHECK_ARG(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldgy >= n, "bad sizes");
+  LNRF_CHECK_ARG(gy && ((x && gw) || (!x && !gw && gb)), "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && n >= 1 && ldgy >= n && (!x || (k >= 1 && ldx >= k)), "bad sizes");
   if (m == 0) return LNRF_OK;
-  // gw[kk][j] += sum_m x[m][kk] * gy[m][j]: A(i=kk, r=m) = x[m*ldx + kk]
-  const int tiles = ((k + TI - 1) / TI) * ((n + TJ - 1) / TJ);
-  int splits = (int)((2048 + tiles - 1) / tiles);
-  const int64_t max_splits = (m + 255) / 256;
-  if (splits > max_splits) splits = (int)max_splits;
-  int rc = launch_gemm(x, 1, ldx, gy, ldgy, 1, gw, n, nullptr, 0, 2, k, n, m, splits, as_stream(stream));
-  if (rc != LNRF_OK) return rc;
+  if (x) {
+    // gw[kk][j] += sum_m x[m][kk] * gy[m][j]: A(i=kk, r=m) = x[m*ldx + kk]
+    const int tiles = ((k + TI - 1) / TI) * ((n + TJ - 1) / TJ);
+    int splits = (int)((2048 + tiles - 1) / tiles);
+    const int64_t max_splits = (m + 255) / 256;
+    if (splits > max_splits) splits = (int)max_splits;
+    int rc = launch_gemm(x, 1, ldx, gy, ldgy, 1, gw, n, nullptr, 0, 2, k, n, m, splits, as_stream(stream));
+    if (rc != LNRF_OK) return rc;
+  }
   if (gb) {
     hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0,
                        as_stream(stream), gy, ldgy, m, n, gb);
@@ -236,4 +238,22 @@ extern "C" int lnrf_sinusoidal_emb(const float* x, int64_t ldx, int64_t m, int32
                      ldx, m, dims, freqs, out, ldo, col_off);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
+}
+
+extern "C" int lnrf_gemm_f32(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r,
+                             int64_t sb_j, float* c, int64_t ldc, const float* bias, int32_t act, int32_t mode,
+                             int64_t i_rows, int32_t j_cols, int64_t r_depth, int32_t splits,
+                             lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(a && b && c, "null pointer");
+  LNRF_CHECK_ARG(i_rows >= 0 && j_cols >= 0 && r_depth >= 1 && ldc >= j_cols, "bad sizes");
+  LNRF_CHECK_ARG(mode >= 0 && mode <= 2 && act >= 0 && act <= LNRF_ACT_SIGMOID, "bad mode/activation");
+  if (mode != 2) splits = 1;
+  if (mode == 2 && splits <= 0) {
+    const int64_t tiles = ((i_rows + TI - 1) / TI) * ((j_cols + TJ - 1) / TJ);
+    splits = (int)((2048 + tiles - 1) / (tiles > 0 ? tiles : 1));
+    const int64_t max_splits = (r_depth + 255) / 256;
+    if (splits > max_splits) splits = (int)max_splits;
+  }
+  return launch_gemm(a, sa_i, sa_r, b, sb_r, sb_j, c, ldc, bias, act, mode, i_rows, j_cols, r_depth, splits,
+                     as_stream(stream));
 }

@@ -1,0 +1,179 @@
+// hashgrid.hip — multiresolution hash-grid encoding of Instant-NGP as restated by the reference:
+// HashTableEncoding.__call__ (learn_nerf/instant_ngp.py:134-208), hash_table_lookup (:211-224),
+// MultiresHashTableEncoding (:92-118).  F = 2 features per entry, fp32 tables as in the reference.
+//
+// MI355X mapping: the gather is bound by L2 / Infinity-Cache / HBM random access, not by FLOPs.  The
+// launch is LEVEL-MAJOR: blockIdx.y = level, so all CUs sweep the points of one level at a time and that
+// level's table (<= 2 MiB at T = 2^18, 4 MiB at 2^19) stays resident in every XCD's 4 MiB L2 instead of
+// 16 tables thrashing it.  The encoding is written feature-major ([L*F][M]) so that both the gather
+// kernel's stores and the scatter kernel's gradient loads are fully coalesced; the tiny MLP reads it
+// through the strided GEMM.
+#include <string.h>
+
+#include "common.h"
+
+namespace lnrf {
+
+constexpr int kMaxLevels = 32;
+
+struct HashGridDesc {  // mirrors lnrf_hashgrid_desc
+  int n_levels, feature_dim, smooth, pad_;
+  float bbox_min[3], bbox_max[3];
+  int grid_size[kMaxLevels];
+  int table_size[kMaxLevels];         // entries (rows) of the level's table
+  long long table_offset[kMaxLevels]; // first float of the level's table in the flat buffer
+  int hashed[kMaxLevels];             // 1: XOR-prime hash, 0: dense x + G (y + G z)
+};
+
+struct Corner {
+  unsigned base[3];  // floored cell
+  float c[3];        // interpolation fraction (after smoothstep if smooth)
+};
+
+__device__ __forceinline__ Corner locate(const float x[3], const HashGridDesc& d, int G) {
+  Corner r;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float frac = (x[a] - d.bbox_min[a]) / (d.bbox_max[a] - d.bbox_min[a]);   // instant_ngp.py:138-140
+    frac = fminf(fmaxf(frac, 0.0f), 1.0f);
+    const float fi = d.smooth ? 0.5f + (float)(G - 2) * frac : (float)(G - 1) * frac;  // :141-146
+    float fl = floorf(fi);
+    fl = fminf(fl, (float)(G - 2));                                           // :150
+    float c = fi - fl;                                                        // :152
+    if (d.smooth) c = (c * c) * (3.0f - 2.0f * c);                            // :153-154
+    r.base[a] = (unsigned)fl;                                                 // :156
+    r.c[a] = c;
+  }
+  return r;
+}
+
+__device__ __forceinline__ unsigned entry_index(unsigned cx, unsigned cy, unsigned cz, int G, int T, int hashed) {
+  if (hashed) return (cx ^ (19349663u * cy) ^ (83492791u * cz)) % (unsigned)T;  // instant_ngp.py:219-223
+  return cx + (unsigned)G * (cy + (unsigned)G * cz);                            // :199-201
+}
+
+// enc_t[(2*level + f) * M + m]
+__global__ void hashgrid_fwd_kernel(HashGridDesc d, const float* __restrict__ tables,
+                                    const float* __restrict__ x, int64_t M, float* __restrict__ enc_t) {
+  const int level = blockIdx.y;
+  const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
+  const float2* __restrict__ tab = reinterpret_cast<const float2*>(tables + d.table_offset[level]);
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    const Corner k = locate(p, d, G);
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+      for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+        for (int zo = 0; zo < 2; ++zo) {  // instant_ngp.py:160-175: weight = prod(o ? c : 1 - c)
+          const float w = (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) *
+                          (zo ? k.c[2] : 1.0f - k.c[2]);
+          const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
+          const float2 v = tab[idx];
+          acc.x += w * v.x;
+          acc.y += w * v.y;
+        }
+    enc_t[(int64_t)(2 * level) * M + m] = acc.x;
+    enc_t[(int64_t)(2 * level + 1) * M + m] = acc.y;
+  }
+}
+
+// g_tables[level][idx][f] += w * g_enc_t[(2*level+f)*M + m].  Levels whose whole table fits in LDS
+// (G^3 * 8 B <= 64 KiB, i.e. the 16^3 levels that thousands of samples share) are pre-reduced in LDS and
+// flushed once per workgroup; the other levels use fp32 atomics directly.
+__global__ void hashgrid_bwd_kernel(HashGridDesc d, const float* __restrict__ x, int64_t M,
+                                    const float* __restrict__ g_enc_t, float* __restrict__ g_tables) {
+  extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+  const int level = blockIdx.y;
+  const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
+  float* __restrict__ gtab = g_tables + d.table_offset[level];
+  const bool in_lds = !hashed && (int64_t)T * 2 * 4 <= 64 * 1024;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < T * 2; i += blockDim.x) lds_tab[i] = 0.0f;
+    __syncthreads();
+  }
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    const Corner k = locate(p, d, G);
+    const float g0 = g_enc_t[(int64_t)(2 * level) * M + m];
+    const float g1 = g_enc_t[(int64_t)(2 * level + 1) * M + m];
+#pragma unroll
+    for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+      for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+        for (int zo = 0; zo < 2; ++zo) {
+          const float w = (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) *
+                          (zo ? k.c[2] : 1.0f - k.c[2]);
+          const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
+          if (in_lds) {
+            atomicAdd(&lds_tab[2 * idx], w * g0);
+            atomicAdd(&lds_tab[2 * idx + 1], w * g1);
+          } else {
+            atomicAdd(gtab + 2 * (int64_t)idx, w * g0);
+            atomicAdd(gtab + 2 * (int64_t)idx + 1, w * g1);
+          }
+        }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * 2; i += blockDim.x) {
+      const float v = lds_tab[i];
+      if (v != 0.0f) atomicAdd(gtab + i, v);
+    }
+  }
+}
+
+}  // namespace lnrf
+
+using namespace lnrf;
+
+static int check_desc(const lnrf_hashgrid_desc* d) {
+  if (!d) { set_error("hashgrid: null descriptor"); return LNRF_ERR_ARG; }
+  if (d->n_levels < 1 || d->n_levels > kMaxLevels) { set_error("hashgrid: n_levels out of range"); return LNRF_ERR_ARG; }
+  if (d->feature_dim != 2) {
+    set_error("hashgrid: only feature_dim == 2 is implemented (the reference default)");
+    return LNRF_ERR_UNSUPPORTED;
+  }
+  for (int l = 0; l < d->n_levels; ++l)
+    if (d->grid_size[l] < 2 || d->table_size[l] < 1) { set_error("hashgrid: bad level"); return LNRF_ERR_ARG; }
+  return LNRF_OK;
+}
+
+static_assert(sizeof(HashGridDesc) == sizeof(lnrf_hashgrid_desc), "descriptor layout");
+
+extern "C" int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, int64_t m,
+                                 float* enc_t, lnrf_stream_t stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  LNRF_CHECK_ARG(tables && x && enc_t, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  HashGridDesc d;
+  memcpy((void*)&d, (const void*)desc, sizeof(d));
+  int64_t bx = (m + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)bx, (unsigned)d.n_levels), dim3(256), 0, as_stream(stream),
+                     d, tables, x, m, enc_t);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m, const float* g_enc_t,
+                                 float* g_tables, lnrf_stream_t stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  LNRF_CHECK_ARG(x && g_enc_t && g_tables, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  HashGridDesc d;
+  memcpy((void*)&d, (const void*)desc, sizeof(d));
+  int64_t bx = (m + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)bx, (unsigned)d.n_levels), dim3(256), 64 * 1024,
+                     as_stream(stream), d, x, m, g_enc_t, g_tables);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}

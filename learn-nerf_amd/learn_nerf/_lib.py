@@ -16,6 +16,12 @@ _DEFAULT = os.path.normpath(os.path.join(_HERE, "..", "lib", "liblnrf.so"))
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH, ACT_EXP, ACT_SIGMOID = range(6)
 
 
+class HashGridDesc(ctypes.Structure):
+    _fields_ = [("n_levels", c_int32), ("feature_dim", c_int32), ("smooth", c_int32), ("pad_", c_int32),
+                ("bbox_min", c_float * 3), ("bbox_max", c_float * 3), ("grid_size", c_int32 * 32),
+                ("table_size", c_int32 * 32), ("table_offset", c_int64 * 32), ("hashed", c_int32 * 32)]
+
+
 class NerfShape(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in
                 ("input_layers", "mid_layers", "hidden_dim", "color_layer_dim", "x_freqs", "d_freqs")]
@@ -45,6 +51,10 @@ PROTOTYPES = {
     "lnrf_act_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int64, c_int32, _P]),
     "lnrf_dense_bwd_input": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, c_int32, c_int32, _P]),
     "lnrf_dense_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P]),
+    "lnrf_gemm_f32": (c_int32, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int32, c_int32,
+                                c_int64, c_int32, c_int64, c_int32, _P]),
+    "lnrf_hashgrid_fwd": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P]),
+    "lnrf_hashgrid_bwd": (c_int32, [POINTER(HashGridDesc), _P, c_int64, _P, _P, _P]),
     "lnrf_nerf_param_count": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_packed_bytes": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_save_bytes": (c_int64, [POINTER(NerfShape), c_int64]),

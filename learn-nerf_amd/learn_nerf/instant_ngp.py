@@ -1,0 +1,243 @@
+"""
+learn_nerf.instant_ngp — InstantNGPModel, MultiresHashTableEncoding, HashTableEncoding,
+hash_table_lookup (reference: learn_nerf/instant_ngp.py).
+
+The multiresolution hash-grid gather / scatter-add are HIP kernels (csrc/hashgrid.hip, level-major
+sweep so one level's table stays L2-resident); the tiny MLP runs on the exact-fp32 strided GEMM.
+Parameter tree names follow Flax: MultiresHashTableEncoding_0/HashTableEncoding_{l}/table, Dense_0..4.
+"""
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import _prof
+from . import ops
+from .model import ModelBase
+from .params import lecun_normal_
+
+F32 = torch.float32
+
+
+def _level_rows(grid_size: int, table_size: int) -> Tuple[int, bool]:
+    hashed = grid_size ** 3 > table_size  # instant_ngp.py:178
+    return (table_size if hashed else grid_size ** 3), hashed
+
+
+def hash_table_lookup(table: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """
+    Lookup integer coordinates [N x 3] in a hash table [T x F] (instant_ngp.py:211-224); uint32
+    wrap-around hash (x ^ 19349663*y ^ 83492791*z) mod T.  Host-level utility (index arithmetic only).
+    """
+    c = coords.to(torch.int64) & 0xFFFFFFFF
+    idx = (c[:, 0] ^ ((19_349_663 * c[:, 1]) & 0xFFFFFFFF) ^ ((83_492_791 * c[:, 2]) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    return table[idx % table.shape[0]]
+
+
+@dataclass
+class MultiresHashTableEncoding:
+    """
+    Encode spatial coordinates with a multiresolution hash table (instant_ngp.py:92-118).
+    apply(tables_flat, x[N,3]) -> [N, L*F].
+    """
+
+    table_sizes: Sequence[int]
+    grid_sizes: Sequence[int]
+    bbox_min: Sequence[float]
+    bbox_max: Sequence[float]
+    feature_dim: int = 2
+    smooth: bool = False
+
+    def rows(self) -> List[int]:
+        return [_level_rows(g, t)[0] for t, g in zip(self.table_sizes, self.grid_sizes)]
+
+    def num_table_floats(self) -> int:
+        return sum(r * self.feature_dim for r in self.rows())
+
+    def desc(self) -> L.HashGridDesc:
+        d = L.HashGridDesc()
+        d.n_levels, d.feature_dim, d.smooth = len(self.grid_sizes), self.feature_dim, int(self.smooth)
+        for a in range(3):
+            d.bbox_min[a] = float(self.bbox_min[a])
+            d.bbox_max[a] = float(self.bbox_max[a])
+        off = 0
+        for l, (t, g) in enumerate(zip(self.table_sizes, self.grid_sizes)):
+            rows, hashed = _level_rows(g, t)
+            d.grid_size[l], d.table_size[l], d.table_offset[l], d.hashed[l] = g, rows, off, int(hashed)
+            off += rows * self.feature_dim
+        return d
+
+    def encode_t(self, tables_flat: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """feature-major encoding [L*F, N] (the layout the kernels use)"""
+        return ops.hashgrid_fwd(self.desc(), tables_flat, x.contiguous())
+
+    def apply(self, tables_flat: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        return self.encode_t(tables_flat, x).t().contiguous()
+
+
+@dataclass
+class HashTableEncoding(MultiresHashTableEncoding):
+    """Single-level encoding (instant_ngp.py:121-208): HashTableEncoding(table_size, grid_size, bbox...)."""
+
+    def __init__(self, table_size: int, grid_size: int, bbox_min, bbox_max, feature_dim: int = 2,
+                 smooth: bool = False):
+        super().__init__([table_size], [grid_size], bbox_min, bbox_max, feature_dim, smooth)
+
+
+@dataclass
+class InstantNGPModel(ModelBase):
+    """A NeRF model that utilizes a multilevel hash table (instant_ngp.py:16-54)."""
+
+    table_sizes: Sequence[int] = None
+    grid_sizes: Sequence[int] = None
+    bbox_min: Sequence[float] = None
+    bbox_max: Sequence[float] = None
+    table_feature_dim: int = 2
+    table_smooth: bool = False
+    d_freqs: int = 4
+    hidden_dim: int = 64
+    density_dim: int = 16
+    density_layers: int = 1
+    color_layers: int = 2
+    tag: str = "ngp"
+
+    def encoding(self) -> MultiresHashTableEncoding:
+        return MultiresHashTableEncoding(self.table_sizes, self.grid_sizes, self.bbox_min, self.bbox_max,
+                                         self.table_feature_dim, self.table_smooth)
+
+    def dense_dims(self) -> List[Tuple[int, int]]:
+        dims, fan = [], len(self.grid_sizes) * self.table_feature_dim
+        for _ in range(self.density_layers):
+            dims.append((fan, self.hidden_dim))
+            fan = self.hidden_dim
+        dims.append((fan, self.density_dim))
+        fan = 6 * self.d_freqs + self.density_dim
+        for _ in range(self.color_layers):
+            dims.append((fan, self.hidden_dim))
+            fan = self.hidden_dim
+        dims.append((fan, 3))
+        return dims
+
+    def param_spec(self):
+        spec = []
+        for l, r in enumerate(self.encoding().rows()):
+            spec.append((f"MultiresHashTableEncoding_0/HashTableEncoding_{l}", "table", (r, self.table_feature_dim)))
+        for i, (fi, fo) in enumerate(self.dense_dims()):
+            spec.append((f"Dense_{i}", "kernel", (fi, fo)))
+            spec.append((f"Dense_{i}", "bias", (fo,)))
+        return spec
+
+    def init_flat_(self, flat, gen):
+        nt = self.encoding().num_table_floats()
+        u = torch.rand(nt, generator=gen, dtype=torch.float32)
+        flat[:nt] = 1e-4 * (u * 2 - 1)  # instant_ngp.py:181-185
+        off = nt
+        for fi, fo in self.dense_dims():
+            lecun_normal_(flat[off:off + fi * fo].view(fi, fo), fi, gen)
+            off += fi * fo + fo
+
+    def _dense_views(self, flat):
+        nt = self.encoding().num_table_floats()
+        out, off = [], nt
+        for fi, fo in self.dense_dims():
+            k = flat[off:off + fi * fo].view(fi, fo)
+            off += fi * fo
+            b = flat[off:off + fo]
+            off += fo
+            out.append((k, b))
+        return flat[:nt], out
+
+    def forward_points(self, flat, x, d, save: bool):
+        enc = self.encoding()
+        tables, W = self._dense_views(flat)
+        m, dev = x.shape[0], flat.device
+        lf = len(self.grid_sizes) * self.table_feature_dim
+        de_w = 6 * self.d_freqs
+        with _prof.section(f"{self.tag}_hashgrid_fwd"):
+            enc_t = enc.encode_t(tables, x)  # [L*F, M]
+        with _prof.section(f"{self.tag}_mlp_fwd"):
+            acts = []
+            li = 0
+            h = torch.empty((m, self.hidden_dim), dtype=F32, device=dev)
+            ops.gemm(enc_t, 1, m, W[0][0], self.hidden_dim, 1, h, self.hidden_dim, m, self.hidden_dim, lf,
+                     bias=W[0][1], act=L.ACT_RELU)  # Dense_0 on the feature-major encoding
+            acts.append(h)
+            li = 1
+            for _ in range(self.density_layers - 1):
+                h = ops.dense_fwd(h, W[li][0], W[li][1], L.ACT_RELU)
+                acts.append(h)
+                li += 1
+            cat = torch.empty((m, de_w + self.density_dim), dtype=F32, device=dev)  # [d_emb, out] (:50)
+            out = ops.dense_fwd(h, W[li][0], W[li][1], L.ACT_NONE, out=cat[:, de_w:])
+            li += 1
+            ops.sinusoidal_emb_into(d, self.d_freqs, cat, 0)
+            e0 = torch.zeros((self.density_dim, 1), dtype=F32, device=dev)
+            e0[0, 0] = 1.0
+            density = ops.dense_fwd(out, e0, None, L.ACT_EXP)  # exp(out[:, :1]) (:49), unclamped
+            c = cat
+            cacts = []
+            for _ in range(self.color_layers):
+                c = ops.dense_fwd(c, W[li][0], W[li][1], L.ACT_RELU)
+                cacts.append(c)
+                li += 1
+            rgb = ops.dense_fwd(c, W[li][0], W[li][1], L.ACT_TANH)
+        ctx = None
+        if save:
+            ctx = dict(flat=flat, x=x, enc_t=enc_t, acts=acts, cat=cat, cacts=cacts, density=density, rgb=rgb, e0=e0)
+        return density.view(-1), rgb, {}, ctx
+
+    def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+        enc = self.encoding()
+        tables, W = self._dense_views(ctx["flat"])
+        g_tables, G = self._dense_views(grad_flat)
+        m = ctx["x"].shape[0]
+        lf = len(self.grid_sizes) * self.table_feature_dim
+        de_w = 6 * self.d_freqs
+        cat, cacts, acts = ctx["cat"], ctx["cacts"], ctx["acts"]
+        with _prof.section(f"{self.tag}_mlp_bwd"):
+            li = len(W) - 1
+            gy = ops.act_bwd_(g_rgb.reshape(-1, 3).clone(), ctx["rgb"], L.ACT_TANH)
+            for i in reversed(range(self.color_layers)):
+                ops.dense_bwd_weight(cacts[i], gy, G[li][0], G[li][1])
+                gh = ops.dense_bwd_input(gy, W[li][0])
+                gy = ops.act_bwd_(gh, cacts[i], L.ACT_RELU)
+                li -= 1
+            ops.dense_bwd_weight(cat, gy, G[li][0], G[li][1])
+            gcat = ops.dense_bwd_input(gy, W[li][0])  # [M, 24 + density_dim]
+            g_out = gcat[:, de_w:]
+            gd = ops.act_bwd_(g_density.reshape(-1, 1).clone(), ctx["density"], L.ACT_EXP)
+            ops.dense_bwd_input(gd, ctx["e0"], out=g_out, accumulate=True)  # d exp(out0) / d out0
+            li -= 1
+            h = acts[-1]
+            ops.dense_bwd_weight(h, g_out, G[li][0], G[li][1])
+            gh = ops.dense_bwd_input(g_out, W[li][0])
+            gy = ops.act_bwd_(gh, h, L.ACT_RELU)
+            li -= 1
+            for i in reversed(range(1, self.density_layers)):
+                ops.dense_bwd_weight(acts[i - 1], gy, G[li][0], G[li][1])
+                gh = ops.dense_bwd_input(gy, W[li][0])
+                gy = ops.act_bwd_(gh, acts[i - 1], L.ACT_RELU)
+                li -= 1
+            # Dense_0: input is the feature-major encoding
+            hd = self.hidden_dim
+            ops.gemm(ctx["enc_t"], m, 1, gy, hd, 1, G[0][0], hd, lf, hd, m, mode=2)  # gW0 += enc^T gy
+            ops.bias_grad(gy, G[0][1])
+            g_enc_t = torch.empty((lf, m), dtype=F32, device=grad_flat.device)
+            ops.gemm(W[0][0], hd, 1, gy, 1, hd, g_enc_t, m, lf, m, hd)  # g_enc^T = W0 gy^T
+        with _prof.section(f"{self.tag}_hashgrid_bwd"):
+            ops.hashgrid_bwd(enc.desc(), ctx["x"], g_enc_t, g_tables)
+
+
+@dataclass
+class InstantNGPRefNERFModel(ModelBase):
+    """instant_ngp.py:57-89 (Ref-NeRF head on a smooth hash grid): not built yet."""
+
+    sh_degree: int = 4
+    table_sizes: Sequence[int] = None
+    grid_sizes: Sequence[int] = None
+    bbox_min: Sequence[float] = None
+    bbox_max: Sequence[float] = None
+
+    def param_spec(self):
+        raise NotImplementedError("InstantNGPRefNERFModel is not implemented in this build (see DESIGN.md section 7)")

@@ -201,6 +201,38 @@ def dense_bwd_weight(x: torch.Tensor, gy: torch.Tensor, gw: torch.Tensor, gb: Op
                                           L.stream()), "dense_bwd_weight")
 
 
+def bias_grad(gy: torch.Tensor, gb: torch.Tensor):
+    m, n = gy.shape
+    L.check(L.lib().lnrf_dense_bwd_weight(None, 0, _vptr(gy), _ld(gy), None, L.ptr(gb), m, 0, n, L.stream()),
+            "bias_grad")
+
+
+def gemm(a: torch.Tensor, sa_i: int, sa_r: int, b: torch.Tensor, sb_r: int, sb_j: int, c: torch.Tensor, ldc: int,
+         i_rows: int, j_cols: int, r_depth: int, bias=None, act: int = 0, mode: int = 0, splits: int = 0):
+    """C[i*ldc+j] (op)= sum_r A[i*sa_i + r*sa_r] * B[r*sb_r + j*sb_j] (see lnrf_gemm_f32)."""
+    L.check(L.lib().lnrf_gemm_f32(_vptr(a), sa_i, sa_r, _vptr(b), sb_r, sb_j, _vptr(c), ldc, L.ptr(bias), act, mode,
+                                  i_rows, j_cols, r_depth, splits, L.stream()), "gemm_f32")
+    return c
+
+
+def hashgrid_fwd(desc, tables: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    import ctypes
+
+    m = x.shape[0]
+    enc_t = torch.empty((desc.n_levels * desc.feature_dim, m), dtype=F32, device=_dev(x))
+    L.check(L.lib().lnrf_hashgrid_fwd(ctypes.byref(desc), L.ptr(tables), L.ptr(x), m, L.ptr(enc_t), L.stream()),
+            "hashgrid_fwd")
+    return enc_t
+
+
+def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor):
+    import ctypes
+
+    m = x.shape[0]
+    L.check(L.lib().lnrf_hashgrid_bwd(ctypes.byref(desc), L.ptr(x), m, L.ptr(g_enc_t), L.ptr(g_tables), L.stream()),
+            "hashgrid_bwd")
+
+
 # ---------------------------------------------------------------- optimiser
 
 def adam_step_(p, g, m, v, lr, b1, b2, eps, step: int, grad_scale: float = 1.0):

@@ -1,0 +1,153 @@
+"""
+GPU parity of the hash-grid path (instant_ngp.py:34-54, 92-224): gather kernel, scatter-add kernel and
+InstantNGPModel forward / backward / train step against the oracle on identical tables and points.
+fp32 kernels vs float64 oracle; scatter-add sums fp32 atomics in arbitrary order (tolerance stated).
+"""
+import pytest
+import torch
+
+from oracle import instant_ngp as ON
+from oracle import philox
+from oracle import train as OT
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+BMIN, BMAX = (-1.0, -0.5, -2.0), (1.0, 1.5, 0.5)
+
+
+def points(m, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    lo, hi = torch.tensor(BMIN), torch.tensor(BMAX)
+    x = torch.rand(m, 3, generator=gen) * (hi - lo) * 1.1 + lo - 0.05 * (hi - lo)  # some just outside the box
+    x[:3] = torch.stack([lo, hi, (lo + hi) / 2])  # corners / centre exactly
+    d = torch.randn(m, 3, generator=gen)
+    return x.float().contiguous(), (d / d.norm(dim=-1, keepdim=True)).float().contiguous(), gen
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+@pytest.mark.parametrize("cfg", [([2 ** 10] * 4, [4, 8, 16, 64]), ([2 ** 14] * 6, [16, 16, 32, 32, 64, 64])])
+def test_hashgrid_fwd_bwd(cfg, smooth):
+    from learn_nerf.instant_ngp import MultiresHashTableEncoding
+
+    ts, gs = cfg
+    enc = MultiresHashTableEncoding(ts, gs, BMIN, BMAX, 2, smooth)
+    m = 3000
+    x, _, gen = points(m)
+    tables = (torch.rand(enc.num_table_floats(), generator=gen) * 2 - 1).float()
+    out = enc.apply(tables.cuda(), x.cuda())
+    assert out.shape == (m, 2 * len(gs))
+    t64 = tables.double().requires_grad_(True)
+    off, feats = 0, []
+    for r, t, g in zip(enc.rows(), ts, gs):
+        feats.append(ON.hash_table_encoding(x.double(), t64[off:off + 2 * r].reshape(r, 2), g, t,
+                                            torch.tensor(BMIN, dtype=F64), torch.tensor(BMAX, dtype=F64), smooth))
+        off += 2 * r
+    ref = torch.cat(feats, 1)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5  # fp32 cell coordinates at G = 64
+    g_enc = torch.randn(m, 2 * len(gs), generator=gen).float()
+    (g_ref,) = torch.autograd.grad((ref * g_enc.double()).sum(), t64)
+    from learn_nerf import ops
+
+    g_tab = torch.zeros_like(tables).cuda()
+    ops.hashgrid_bwd(enc.desc(), x.cuda(), g_enc.t().contiguous().cuda(), g_tab)
+    err = (g_tab.cpu().double() - g_ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, g_ref.abs().max().item())
+
+
+def make_model(levels, table, hidden=64, seed=2):
+    from learn_nerf.instant_ngp import InstantNGPModel
+
+    model = InstantNGPModel(table_sizes=[table] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)],
+                            bbox_min=BMIN, bbox_max=BMAX, hidden_dim=hidden)
+    params = model.init(dict(params=seed))["params"]
+    flat = model.flat(params)
+    nt = model.encoding().num_table_floats()
+    gen = torch.Generator().manual_seed(seed)
+    flat[:nt] = ((torch.rand(nt, generator=gen) * 2 - 1) * 0.5).cuda()  # U(-1e-4,1e-4) init would hide gather errors
+    return model, params, flat
+
+
+@pytest.mark.parametrize("levels,table", [(6, 2 ** 12), (16, 2 ** 14)])
+def test_ngp_model_forward_backward(levels, table):
+    model, params, flat = make_model(levels, table)
+    assert model.num_params() == ON.ngp_param_count(model.table_sizes, model.grid_sizes)
+    m = 2500
+    x, d, gen = points(m, seed=levels)
+    dens, rgb, aux = model.apply(dict(params=params), x.cuda(), d.cuda())
+    f64 = flat.cpu().double().requires_grad_(True)
+    rd, rr, _ = ON.ngp_model(f64, x.double(), d.double(), model.table_sizes, model.grid_sizes, BMIN, BMAX)
+    assert aux == {} and dens.shape == (m, 1)
+    assert (rgb.cpu().double() - rr).abs().max().item() < 1e-4
+    assert ((dens.cpu().double() - rd).abs() / (1 + rd.abs())).max().item() < 1e-4
+    g_d = torch.randn(m, generator=gen).float()
+    g_c = torch.randn(m, 3, generator=gen).float()
+    (g_ref,) = torch.autograd.grad((rd[:, 0] * g_d.double()).sum() + (rr * g_c.double()).sum(), f64)
+    _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+    grad = torch.zeros_like(flat)
+    model.backward(ctx, g_d.cuda(), g_c.cuda(), None, grad)
+    nt = model.encoding().num_table_floats()
+    got = grad.cpu().double()
+    # The reference arithmetic is fp32: at G = 2048 the fp32 cell coordinate (G-1)*frac carries ~1e-4 of a
+    # cell, so a float64 evaluation puts a few samples into neighbouring cells.  The table gradient is
+    # therefore compared with the oracle run in float32 (same cells), the float64 figure is printed.
+    f32 = flat.cpu().float().requires_grad_(True)
+    rd32, rr32, _ = ON.ngp_model(f32, x, d, model.table_sizes, model.grid_sizes, BMIN, BMAX)
+    (g_ref32,) = torch.autograd.grad((rd32[:, 0] * g_d).sum() + (rr32 * g_c).sum(), f32)
+    for name, a, b, b32 in (("tables", got[:nt], g_ref[:nt], g_ref32[:nt].double()),
+                            ("mlp", got[nt:], g_ref[nt:], g_ref32[nt:].double())):
+        rel = ((a - b).norm() / b.norm()).item()
+        rel32 = ((a - b32).norm() / b32.norm()).item()
+        print(f"L={levels} {name}: rel L2 err vs float64 oracle {rel:.2e}, vs float32 oracle {rel32:.2e}")
+        assert min(rel, rel32) < 2e-3, (name, rel, rel32)  # ReLU sign flips of the 64-wide MLP are the floor
+        assert rel < 2e-2
+
+
+def test_ngp_train_step_matches_oracle():
+    from learn_nerf.instant_ngp import InstantNGPModel
+    from learn_nerf.rng import Key, split
+    from learn_nerf.train import TrainLoop
+
+    def mk(levels):
+        return InstantNGPModel(table_sizes=[2 ** 12] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)],
+                               bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3)
+
+    n, tc, tf, lr = 128, 16, 32, 1e-2
+    loop = TrainLoop(mk(3), mk(5), init_rng=4, lr=lr, coarse_ts=tc, fine_ts=tf, adam_eps=1e-15, adam_b1=0.9,
+                     adam_b2=0.99)  # scripts/train_nerf.py:161
+    gen = torch.Generator().manual_seed(0)
+    for mdl, sl in ((loop.coarse, loop._slices(loop.flat)[0]), (loop.fine, loop._slices(loop.flat)[1])):
+        nt = mdl.encoding().num_table_floats()
+        sl[:nt] = ((torch.rand(nt, generator=gen) * 2 - 1) * 0.5).cuda()
+    o = torch.randn(n, 3, generator=gen)
+    o = 4 * o / o.norm(dim=-1, keepdim=True)
+    dd = -o + (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+    dd = dd / dd.norm(dim=-1, keepdim=True)
+    batch = torch.stack([o, dd, torch.rand(n, 3, generator=gen) * 2 - 1], 1).float().contiguous()
+    cf, ff, bg = [t.cpu().double() for t in loop._slices(loop.flat)]
+    log = loop.step_fn((-1.0,) * 3, (1.0,) * 3)(77, batch.cuda())
+    rk, _ = split(Key(77), 2)
+    ck, fk = split(rk, 2)
+    uc = torch.from_numpy(philox.ray_uniforms(ck.seed, 0, 0, n, tc)).double()
+    uf = torch.from_numpy(philox.ray_uniforms(fk.seed, 1, 0, n, tf)).double()
+
+    def make_fn(model, fl):
+        return lambda x, d: ON.ngp_model(fl, x, d, model.table_sizes, model.grid_sizes, (-1.0,) * 3, (1.0,) * 3)
+
+    params = [cf.clone().requires_grad_(True), ff.clone().requires_grad_(True), bg.clone().requires_grad_(True)]
+    total, ld, _ = OT.losses(make_fn(loop.coarse, params[0]), make_fn(loop.fine, params[1]), params[2],
+                             torch.tensor([-1.0] * 3, dtype=F64), torch.tensor([1.0] * 3, dtype=F64), batch.double(),
+                             tc, tf, uc, uf)
+    grads = torch.autograd.grad(total, params)
+    ref_grad = torch.cat([g.reshape(-1) for g in grads])
+    rel = ((loop.grad.cpu().double() - ref_grad).norm() / ref_grad.norm()).item()
+    print(f"ngp step: coarse {float(log['coarse']):.6f}/{float(ld['coarse']):.6f} fine {float(log['fine']):.6f}/"
+          f"{float(ld['fine']):.6f} grad rel err {rel:.2e}")
+    assert abs(float(log["coarse"]) - float(ld["coarse"])) < 1e-5
+    assert abs(float(log["fine"]) - float(ld["fine"])) < 1e-5
+    assert rel < 5e-3
+    new = [OT.adam_update(p.detach(), g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, 0.9, 0.99, 1e-15)[0]
+           for p, g in zip(params, grads)]
+    upd = (loop.flat.cpu().double() - torch.cat([t.reshape(-1) for t in new])).abs()
+    # entries with (numerically) zero gradient move by +-lr under eps = 1e-15 depending on rounding noise
+    big = ref_grad.abs() > 1e-9
+    assert upd[big].max().item() < 1e-4
