@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="nerf", choices=["nerf", "ngp"],
+                    help="nerf = BASELINE configs[1] (the metric's config, default); ngp = configs[2] hash-grid path")
+    ap.add_argument("--table_log2", type=int, default=19, help="ngp: log2 of the hash table size (configs[2]: 19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -119,8 +122,19 @@ def main():
     from learn_nerf.train import TrainLoop
 
     n = args.rays
-    loop = TrainLoop(NeRFModel(precision=args.precision), NeRFModel(precision=args.precision), init_rng=0, lr=1e-4,
-                     coarse_ts=COARSE, fine_ts=FINE, device=device)
+    if args.workload == "ngp":
+        from learn_nerf.instant_ngp import InstantNGPModel
+
+        def ngp(levels):  # scripts/train_nerf.py:150-161 with the table size of BASELINE configs[2]
+            return InstantNGPModel(table_sizes=[2 ** args.table_log2] * levels,
+                                   grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], bbox_min=BBOX_MIN,
+                                   bbox_max=BBOX_MAX)
+
+        loop = TrainLoop(ngp(6), ngp(16), init_rng=0, lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, adam_eps=1e-15,
+                         adam_b1=0.9, adam_b2=0.99, device=device)
+    else:
+        loop = TrainLoop(NeRFModel(precision=args.precision), NeRFModel(precision=args.precision), init_rng=0,
+                         lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, device=device)
     if world > 1:  # same initial parameters everywhere (init is seeded, broadcast for safety)
         dist.broadcast(loop.flat, src=0)
     step = loop.step_fn(BBOX_MIN, BBOX_MAX)
@@ -165,22 +179,60 @@ def main():
                     flops = m * 2 * MAC_DGRAD_PER_EVAL
                 elif name.endswith("_bwd_weights"):
                     flops = m * 2 * MAC_WGRAD_PER_EVAL
+            if args.workload != "nerf":
+                flops = None
             fams[name] = dict(ms=round(ms, 4), calls_per_step=cnt / args.steps,
                               tflops=None if flops is None else round(flops / (ms * 1e-3) / 1e12, 1))
         roofline = None
         timed = {k: v for k, v in fams.items() if v["tflops"] is not None}
-        if timed:
+        if args.workload == "ngp":
+            # gather/scatter roofline: L*8 corners*F*4 B per evaluation; scatter-add counted as 2x
+            for name, v in fams.items():
+                lv = 6 if name.startswith("coarse") else 16
+                m = m_c if name.startswith("coarse") else m_f
+                if name.endswith("hashgrid_fwd"):
+                    v["GBps"] = round(m * lv * 8 * 2 * 4 / (v["ms"] * 1e-3) / 1e9, 1)
+                elif name.endswith("hashgrid_bwd"):
+                    v["GBps"] = round(2 * m * lv * 8 * 2 * 4 / (v["ms"] * 1e-3) / 1e9, 1)
+            hg = {k: v for k, v in fams.items() if "GBps" in v}
+            if hg:
+                dom = max(hg, key=lambda k: hg[k]["ms"])
+                roofline = dict(bound="hbm", kernel=dom, achieved=hg[dom]["GBps"], peak=8000.0, unit="GB/s",
+                                frac=round(hg[dom]["GBps"] / 8000.0, 4), traffic=None)
+        elif timed:
+            # Algorithmic HBM bytes per 32-evaluation tile of each kernel family:
+            # forward writes the 167 KiB save block, the backward chain reads 9 KiB of masks and writes
+            # 156 KiB of dy, the weight-gradient kernel reads X and dy fragments (344 KiB).
+            tile_bytes = {"_fwd": 167 * 1024, "_bwd_chain": (156 + 9) * 1024, "_bwd_weights": 344 * 1024}
+            for name, v in timed.items():
+                m = m_c if name.startswith("coarse") else m_f
+                for suffix, b in tile_bytes.items():
+                    if name.endswith(suffix):
+                        v["GBps"] = round((m / 32) * b / (v["ms"] * 1e-3) / 1e9, 1)
             dom = max(timed, key=lambda k: timed[k]["ms"])
-            achieved = timed[dom]["tflops"]
-            roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_FLOPS / 1e12, unit="TFLOP/s",
-                            frac=round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), traffic=None)
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc) and n == RAYS_PER_GPU:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            if dom.endswith("_bwd_weights"):
+                # the dominant kernel streams its operands once from HBM (128 FLOP/B on bf16 dumps): HBM roofline
+                roofline = dict(bound="hbm", kernel=dom, achieved=timed[dom]["GBps"], peak=8000.0, unit="GB/s",
+                                frac=round(timed[dom]["GBps"] / 8000.0, 4), traffic=traffic,
+                                mfma_tflops=timed[dom]["tflops"])
+            else:
+                achieved = timed[dom]["tflops"]
+                roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_FLOPS / 1e12,
+                                unit="TFLOP/s", frac=round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), traffic=traffic)
         step_tflops = (value / world) * FLOP_TRAIN_PER_RAY_SAMPLE / 1e12
         out = dict(
             metric="ray-samples/s (NeRF train step: fwd + bwd + Adam, 4096 rays x 192 samples per GPU)",
             value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype="bf16" if args.precision == "bf16" else "f32", data="synthetic",
-            config=dict(workload="vanilla NeRF coarse64+fine128 train step (BASELINE.json configs[1])",
+            dtype=("bf16" if args.precision == "bf16" else "f32") if args.workload == "nerf" else "f32",
+            data="synthetic",
+            config=dict(workload="vanilla NeRF coarse64+fine128 train step (BASELINE.json configs[1])"
+                        if args.workload == "nerf" else
+                        f"instant_ngp hash-grid L=6/16, T=2^{args.table_log2} train step (BASELINE.json configs[2])",
                         rays_per_gpu=n, coarse_samples=COARSE, fine_samples=FINE, global_batch_rays=world * n,
                         parallelism=f"dp{world}", precision=args.precision + " MFMA, fp32 accumulate/master weights"
                         if args.precision == "bf16" else "fp32 (f32 MFMA)"),
@@ -191,7 +243,7 @@ def main():
             kernels=fams,
             losses={k: round(float(v), 5) for k, v in log.items()},
         )
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "nerf":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:

@@ -79,6 +79,19 @@ NL_HD constexpr int fwd_base(int s) {
 }
 constexpr int kFwdFrags = fwd_base(kFwdLayers);  // 1200
 static_assert(kFwdFrags == 1200, "forward stream length");
+// consumption order: fragments are used layer by layer, skipping the stage-alignment padding
+NL_HD constexpr int fwd_cons_base(int s) {
+  int b = 0;
+  for (int i = 0; i < s; ++i) b += fwd_nk(i) * fwd_no(i);
+  return b;
+}
+constexpr int kFwdUsed = fwd_cons_base(kFwdLayers);  // 1186
+NL_HD constexpr int fwd_seq(int c) {  // c-th consumed fragment -> stream index
+  int s = 0;
+  for (int i = 1; i < kFwdLayers; ++i)
+    if (c >= fwd_cons_base(i)) s = i;
+  return fwd_base(s) + (c - fwd_cons_base(s));
+}
 // fp32 bias block, [stream layer][32*o + row]
 NL_HD constexpr int fwd_bias_base(int s) {
   int b = 0;
@@ -151,6 +164,18 @@ NL_HD constexpr int bwd_base(int t) {
 }
 constexpr int kBwdFrags = bwd_base(kBwdLayers);  // 1120
 static_assert(kBwdFrags == 1120, "backward stream length");
+NL_HD constexpr int bwd_cons_base(int t) {
+  int b = 0;
+  for (int i = 0; i < t; ++i) b += bwd_nk(i) * bwd_no(i);
+  return b;
+}
+constexpr int kBwdUsed = bwd_cons_base(kBwdLayers);  // 1100
+NL_HD constexpr int bwd_seq(int c) {
+  int t = 0;
+  for (int i = 1; i < kBwdLayers; ++i)
+    if (c >= bwd_cons_base(i)) t = i;
+  return bwd_base(t) + (c - bwd_cons_base(t));
+}
 NL_HD constexpr int bwd_dense(int t) { return t == 0 ? 11 : (t == 1 ? 10 : 10 - t); }  // t=2->8 ... t=9->1
 
 NL_HD constexpr int bwd_weight_index(int t, int o, int ks, int lane, int j) {

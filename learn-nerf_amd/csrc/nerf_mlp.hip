@@ -37,10 +37,11 @@ constexpr int kWaves = 8;            // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr int kTileCols = 32;        // evaluations per wave
 constexpr int kStageBytes = kStageFrags * kFragBytes;  // 16 KiB
-constexpr int kSlots = 2;            // LDS stages: one being read, one being written
+constexpr int kSlots = 3;            // LDS stages: being read, published-next, being written
 constexpr int kRingBytes = kSlots * kStageBytes;
 constexpr int kBiasLdsOff = kRingBytes;
 constexpr int kFusedLds = kRingBytes + round_up(kBiasFloats * 4, 1024);
+constexpr int kFragAhead = 4;        // A-fragments read from LDS ahead of the MFMA that uses them
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -48,16 +49,28 @@ __device__ __forceinline__ bf16x8 bits_to_frag(uint4 v) { return __builtin_bit_c
 __device__ __forceinline__ uint4 frag_to_bits(bf16x8 v) { return __builtin_bit_cast(uint4, v); }
 __device__ __forceinline__ bf16x8 zero_frag() { return bits_to_frag(make_uint4(0, 0, 0, 0)); }
 
+struct FwdSeq {
+  static constexpr int count = kFwdUsed;
+  static constexpr int at(int c) { return fwd_seq(c); }
+};
+struct BwdSeq {
+  static constexpr int count = kBwdUsed;
+  static constexpr int at(int c) { return bwd_seq(c); }
+};
+
 // The weight ring.  A stage is 16 fragments (16 KiB) shared by the 8 waves; every wave moves 2 of
 // them.  Staging is global -> VGPR -> LDS (not LDS-DMA: hipcc drains vmcnt(0) before any ds_read
-// while an LDS-DMA is pending, which serialises the pipeline).  Stage T+3 is loaded into registers
-// while stage T is consumed; it is written to LDS two barriers later, so the L2 latency of the
-// (L2-resident, 1.2 MB) weight stream is covered by two stages of MFMA work.
-template <int NSTAGES>
+// while an LDS-DMA is pending, which serialises the pipeline).  Timeline at the barrier that opens
+// stage T: stage T+1 is already in LDS and becomes visible (it was written after barrier T-1), stage
+// T+2 is written from registers into the slot freed by stage T-1, stage T+4 is requested from L2.
+// Because stage T+1 is visible during stage T, the per-wave FIFO of A-fragments (kFragAhead LDS reads
+// in flight) runs continuously across stage boundaries.
+template <int NSTAGES, class SEQ>
 struct Ring {
   const char* stream;  // global, NSTAGES * 16 KiB, fragment order
   int wave, lane;
   uint4 r[2][2];
+  bf16x8 fifo[kFragAhead];
 
   template <int T>
   __device__ __forceinline__ void load() {
@@ -76,23 +89,42 @@ struct Ring {
       *reinterpret_cast<uint4*>(&smem[(T % kSlots) * kStageBytes + f * kFragBytes + lane * 16]) = r[T & 1][q];
     }
   }
+  template <int G>
+  __device__ __forceinline__ bf16x8 read_lds() const {
+    constexpr int off = ((G / kStageFrags) % kSlots) * kStageBytes + (G % kStageFrags) * kFragBytes;
+    return bits_to_frag(*reinterpret_cast<const uint4*>(&smem[off + lane * 16]));
+  }
+  // loads stages 0..3, publishes stages 0 and 1, fills the fragment FIFO
   __device__ __forceinline__ void prologue() {
     load<0>();
     if constexpr (NSTAGES > 1) load<1>();
     write<0>();
+    if constexpr (NSTAGES > 1) write<1>();
     if constexpr (NSTAGES > 2) load<2>();
+    if constexpr (NSTAGES > 3) load<3>();
+    __syncthreads();
+    if constexpr (NSTAGES > 2) write<2>();  // the work of the (implicit) barrier that opens stage 0
+    if constexpr (NSTAGES > 4) load<4>();
+    static_for<kFragAhead>([&](auto i) {
+      constexpr int c = decltype(i)::value;
+      if constexpr (c < SEQ::count) fifo[c] = read_lds<SEQ::at(c)>();
+    });
   }
-  // make stage T visible to the whole workgroup, write stage T+1 into the slot freed by stage T-1
+  // barrier that opens stage T (T >= 1): frees the slot of stage T-1, publishes stage T+1
   template <int T>
   __device__ __forceinline__ void advance() {
     __syncthreads();
-    if constexpr (T + 1 < NSTAGES) write<T + 1>();
-    if constexpr (T + 3 < NSTAGES) load<T + 3>();
+    if constexpr (T + 2 < NSTAGES) write<T + 2>();
+    if constexpr (T + 4 < NSTAGES) load<T + 4>();
   }
-  template <int G>
-  __device__ __forceinline__ bf16x8 frag() const {
-    constexpr int off = ((G / kStageFrags) % kSlots) * kStageBytes + (G % kStageFrags) * kFragBytes;
-    return bits_to_frag(*reinterpret_cast<const uint4*>(&smem[off + lane * 16]));
+  // fragment of consumption index C (and request the one kFragAhead later)
+  template <int C>
+  __device__ __forceinline__ bf16x8 next() {
+    constexpr int g = SEQ::at(C);
+    if constexpr (g % kStageFrags == 0 && g > 0) advance<g / kStageFrags>();
+    const bf16x8 a = fifo[C % kFragAhead];
+    if constexpr (C + kFragAhead < SEQ::count) fifo[C % kFragAhead] = read_lds<SEQ::at(C + kFragAhead)>();
+    return a;
   }
 };
 
@@ -163,17 +195,20 @@ struct DumpAddr {
 };
 
 // One GEMM layer of the fused chain: for each 32-row out tile, for each k-step, one MFMA.
-template <int NSTAGES, int BASE, int NK, int NO, class Init, class GetB, class Epi>
-__device__ __forceinline__ void chain_layer(Ring<NSTAGES>& ring, Init init, GetB getb, Epi epi) {
+// C0 = consumption index of the layer's first fragment.
+template <int C0, int NK, int NO, class RING, class Init, class GetB, class Epi>
+__device__ __forceinline__ void chain_layer(RING& ring, Init init, GetB getb, Epi epi) {
   static_for<NO>([&](auto o_) {
     constexpr int o = decltype(o_)::value;
     f32x16 acc = init(o_);
     static_for<NK>([&](auto k_) {
       constexpr int ks = decltype(k_)::value;
-      constexpr int g = BASE + o * NK + ks;
-      if constexpr (g % kStageFrags == 0) ring.template advance<g / kStageFrags>();
-      const bf16x8 a = ring.template frag<g>();
+      const bf16x8 a = ring.template next<C0 + o * NK + ks>();
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, getb(k_), acc, 0, 0, 0);
+      // keep the software pipeline the source expresses: one LDS fragment read (for the MFMA
+      // kFragAhead steps later) per MFMA, instead of the scheduler's read-wait-use pairs
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
     });
     epi(o_, acc);
   });
@@ -225,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   }
   __syncthreads();
 
-  Ring<kFwdStages> ring;
+  Ring<kFwdStages, FwdSeq> ring;
   ring.stream = packed + kPackFwdOff;
   ring.wave = wave;
   ring.lane = lane;
@@ -282,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   auto hidden = [&](auto s_, bf16x8(&in)[16], bf16x8(&out)[16], auto relu_, int save_slot) {
     constexpr int S = decltype(s_)::value;
     constexpr bool RELU = decltype(relu_)::value;
-    chain_layer<kFwdStages, fwd_base(S), fwd_nk(S), fwd_no(S)>(
+    chain_layer<fwd_cons_base(S), fwd_nk(S), fwd_no(S)>(
         ring, [&](auto o_) { return bias_acc(fwd_bias_base(S) + 32 * decltype(o_)::value, h); },
         [&](auto k_) -> bf16x8 {
           constexpr int ks = decltype(k_)::value;
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   hidden(std::integral_constant<int, 8>{}, a1, a0, lin, kSaveZ);            // Dense_8: linear z (model.py:53-56)
 
   // Dense_10 (+ Dense_9 as row 128): z and d_emb in, relu(h10) and the density logit out
-  chain_layer<kFwdStages, fwd_base(9), fwd_nk(9), fwd_no(9)>(
+  chain_layer<fwd_cons_base(9), fwd_nk(9), fwd_no(9)>(
       ring, [&](auto o_) { return bias_acc(fwd_bias_base(9) + 32 * decltype(o_)::value, h); },
       [&](auto k_) -> bf16x8 {
         constexpr int ks = decltype(k_)::value;
@@ -346,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
         }
       });
   // Dense_11 + tanh (model.py:60)
-  chain_layer<kFwdStages, fwd_base(10), fwd_nk(10), fwd_no(10)>(
+  chain_layer<fwd_cons_base(10), fwd_nk(10), fwd_no(10)>(
       ring, [&](auto) { return bias_acc(fwd_bias_base(10), h); },
       [&](auto k_) -> bf16x8 { return a1[decltype(k_)::value]; },
       [&](auto, const f32x16& acc) {
@@ -395,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
                            : make_uint4(0, 0, 0, 0);
   __syncthreads();
 
-  Ring<kBwdStages> ring;
+  Ring<kBwdStages, BwdSeq> ring;
   ring.stream = packed + kPackBwdOff;
   ring.wave = wave;
   ring.lane = lane;
@@ -417,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   dump_frag(kGradDy11 + 1, zero_frag());
 
   // T0: Dense_11^T -> dh10, masked by relu(h10)
-  chain_layer<kBwdStages, bwd_base(0), bwd_nk(0), bwd_no(0)>(
+  chain_layer<bwd_cons_base(0), bwd_nk(0), bwd_no(0)>(
       ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy11; },
       [&](auto o_, const f32x16& acc) {
         constexpr int o = decltype(o_)::value;
@@ -434,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   dump_frag(kGradDy10m + 9, zero_frag());
 
   // T1: [Dense_10 | Dense_9]^T (z rows) -> dz = dy8 (Dense_8 output is linear)
-  chain_layer<kBwdStages, bwd_base(1), bwd_nk(1), bwd_no(1)>(
+  chain_layer<bwd_cons_base(1), bwd_nk(1), bwd_no(1)>(
       ring, [&](auto) { return zero_acc(); },
       [&](auto k_) -> bf16x8 {
         constexpr int ks = decltype(k_)::value;
@@ -453,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   auto back = [&](auto t_, bf16x8(&in)[16], bf16x8(&out)[16]) {
     constexpr int TT = decltype(t_)::value;
     constexpr int l = bwd_dense(TT);  // dense layer whose transpose is applied
-    chain_layer<kBwdStages, bwd_base(TT), bwd_nk(TT), bwd_no(TT)>(
+    chain_layer<bwd_cons_base(TT), bwd_nk(TT), bwd_no(TT)>(
         ring, [&](auto) { return zero_acc(); },
         [&](auto k_) -> bf16x8 { return in[decltype(k_)::value]; },
         [&](auto o_, const f32x16& acc) {

@@ -171,4 +171,4 @@ def test_losses_no_grad_and_checkpoint_roundtrip(tmp_path):
     loop2.load(path)
     assert torch.equal(loop2.flat, loop.flat)
     t2, _ = loop2.losses(7, BMIN, BMAX, batch)
-    assert float(t2) == float(total)
+    assert abs(float(t2) - float(total)) < 1e-6  # per-block partial sums are combined by fp32 atomics
