@@ -177,6 +177,47 @@ int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const
 int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m, const float* g_enc_t,
                       float* g_tables, lnrf_stream_t stream);
 
+/* ------------------------------------------------------------- Ref-NeRF ---- */
+
+/* Transpose / tangent of d sinusoidal_emb / d x (model.py:65-77), needed by the analytic normals
+ * -d out[:,0]/dx of RefNERFBase (ref_nerf.py:38-43) and by their second-order term:
+ *   bwd: g_x[m,c]   = sum_f 2^f (cos(2^f x) g_emb[sin f] - sin(2^f x) g_emb[cos f])
+ *   jvp: v_emb[...] = (d emb / d x) u,  u [M,dims]. */
+int lnrf_sinusoidal_emb_bwd(const float* x, int64_t ldx, int64_t m, int32_t dims, int32_t freqs,
+                            const float* g_emb, int64_t ldg, int64_t col_off, float* g_x,
+                            lnrf_stream_t stream);
+int lnrf_sinusoidal_emb_jvp(const float* x, int64_t ldx, int64_t m, int32_t dims, int32_t freqs,
+                            const float* u, float* v_emb, int64_t ldv, int64_t col_off,
+                            lnrf_stream_t stream);
+
+/* integrated_directional_encoding (ref_nerf.py:121-143) on spherical_harmonic (:146-311):
+ * out[M, sh_degree^2]; roughness [M] or NULL (plain spherical harmonics). */
+int lnrf_integrated_directional_encoding(int32_t sh_degree, const float* coords, const float* roughness,
+                                         int64_t m, float* out, lnrf_stream_t stream);
+
+/* RefNERFBase.__call__ between spatial_block and directional_block (ref_nerf.py:41-63, 72-75).
+ * spatial: [M, >=9] (row stride lds): density logit, diffuse(3), spectral, roughness, normal(3).
+ * nraw [M,3] = -d sum(out[:,0]) / dx (unnormalised analytic normal), d [M,3] view directions.
+ * Writes density[M], diffuse[M,3], spectral[M], tail[m, 0..sh^2] = IDE of the reflection direction,
+ * tail[m, sh^2] = -d.n  (the columns appended to spatial_out for the directional block), and
+ * aux[M,2] = (normal_mse, neg_normal) per sample. */
+int lnrf_refnerf_head_fwd(const float* spatial, int64_t lds, const float* nraw, const float* d, int64_t m,
+                          int32_t sh_degree, float* density, float* diffuse, float* spectral, float* tail,
+                          int64_t ld_tail, float* aux, lnrf_stream_t stream);
+/* VJP of the above: g_spatial[m, 0..8] += ..., g_nraw[M,3] = ... */
+int lnrf_refnerf_head_bwd(const float* spatial, int64_t lds, const float* nraw, const float* d, int64_t m,
+                          int32_t sh_degree, const float* g_density, const float* g_diffuse,
+                          const float* g_spectral, const float* g_tail, int64_t ld_tail, const float* g_aux,
+                          float* g_spatial, int64_t ldgs, float* g_nraw, lnrf_stream_t stream);
+
+/* full_color = linear_rgb_to_srgb(_leaky_clip(sigmoid(dir_out) * spectral + diffuse)) * 2 - 1
+ * (ref_nerf.py:64-71, 110-118, 320-326) and its VJP. */
+int lnrf_refnerf_color_fwd(const float* dir_out, const float* spectral, const float* diffuse, int64_t m,
+                           float* rgb, lnrf_stream_t stream);
+int lnrf_refnerf_color_bwd(const float* dir_out, const float* spectral, const float* diffuse, int64_t m,
+                           const float* g_rgb, float* g_dir_out, float* g_spectral, float* g_diffuse,
+                           lnrf_stream_t stream);
+
 /* ------------------------------------------------ fused NeRF MLP (bf16 MFMA) ---- */
 
 /* NeRFModel hyper-parameters (model.py:35-40). The fused kernels support the reference

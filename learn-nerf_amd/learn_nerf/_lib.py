@@ -55,6 +55,14 @@ PROTOTYPES = {
                                 c_int64, c_int32, c_int64, c_int32, _P]),
     "lnrf_hashgrid_fwd": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P]),
     "lnrf_hashgrid_bwd": (c_int32, [POINTER(HashGridDesc), _P, c_int64, _P, _P, _P]),
+    "lnrf_sinusoidal_emb_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P]),
+    "lnrf_sinusoidal_emb_jvp": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, c_int64, _P]),
+    "lnrf_integrated_directional_encoding": (c_int32, [c_int32, _P, _P, c_int64, _P, _P]),
+    "lnrf_refnerf_head_fwd": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int64, _P, _P]),
+    "lnrf_refnerf_head_bwd": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int64, _P, _P,
+                                        c_int64, _P, _P]),
+    "lnrf_refnerf_color_fwd": (c_int32, [_P, _P, _P, c_int64, _P, _P]),
+    "lnrf_refnerf_color_bwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "lnrf_nerf_param_count": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_packed_bytes": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_save_bytes": (c_int64, [POINTER(NerfShape), c_int64]),

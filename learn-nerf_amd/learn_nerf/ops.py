@@ -233,6 +233,73 @@ def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.T
             "hashgrid_bwd")
 
 
+# ---------------------------------------------------------------- Ref-NeRF pieces
+
+def sinusoidal_emb_bwd(x: torch.Tensor, freqs: int, g_emb: torch.Tensor, col_off: int = 0) -> torch.Tensor:
+    m, dims = x.shape
+    g_x = torch.empty((m, dims), dtype=F32, device=_dev(x))
+    L.check(L.lib().lnrf_sinusoidal_emb_bwd(_vptr(x), _ld(x), m, dims, freqs, _vptr(g_emb), _ld(g_emb), col_off,
+                                            L.ptr(g_x), L.stream()), "sinusoidal_emb_bwd")
+    return g_x
+
+
+def sinusoidal_emb_jvp_into(x: torch.Tensor, freqs: int, u: torch.Tensor, out: torch.Tensor, col_off: int = 0):
+    m, dims = x.shape
+    L.check(L.lib().lnrf_sinusoidal_emb_jvp(_vptr(x), _ld(x), m, dims, freqs, L.ptr(u), _vptr(out), _ld(out), col_off,
+                                            L.stream()), "sinusoidal_emb_jvp")
+    return out
+
+
+def integrated_directional_encoding(sh_degree: int, coords: torch.Tensor, roughness) -> torch.Tensor:
+    m = coords.shape[0]
+    out = torch.empty((m, sh_degree * sh_degree), dtype=F32, device=_dev(coords))
+    L.check(L.lib().lnrf_integrated_directional_encoding(sh_degree, L.ptr(coords), L.ptr(roughness), m, L.ptr(out),
+                                                         L.stream()), "integrated_directional_encoding")
+    return out
+
+
+def refnerf_head_fwd(spatial: torch.Tensor, nraw, d, sh_degree: int, tail: torch.Tensor):
+    m = spatial.shape[0]
+    dev = _dev(spatial)
+    density = torch.empty(m, dtype=F32, device=dev)
+    diffuse = torch.empty((m, 3), dtype=F32, device=dev)
+    spectral = torch.empty(m, dtype=F32, device=dev)
+    aux = torch.empty((m, 2), dtype=F32, device=dev)
+    L.check(L.lib().lnrf_refnerf_head_fwd(_vptr(spatial), _ld(spatial), L.ptr(nraw), L.ptr(d), m, sh_degree,
+                                          L.ptr(density), L.ptr(diffuse), L.ptr(spectral), _vptr(tail), _ld(tail),
+                                          L.ptr(aux), L.stream()), "refnerf_head_fwd")
+    return density, diffuse, spectral, aux
+
+
+def refnerf_head_bwd(spatial, nraw, d, sh_degree: int, g_density, g_diffuse, g_spectral, g_tail, g_aux, g_spatial):
+    m = spatial.shape[0]
+    g_nraw = torch.empty((m, 3), dtype=F32, device=_dev(spatial))
+    L.check(L.lib().lnrf_refnerf_head_bwd(_vptr(spatial), _ld(spatial), L.ptr(nraw), L.ptr(d), m, sh_degree,
+                                          L.ptr(g_density), L.ptr(g_diffuse), L.ptr(g_spectral), _vptr(g_tail),
+                                          _ld(g_tail), L.ptr(g_aux), _vptr(g_spatial), _ld(g_spatial), L.ptr(g_nraw),
+                                          L.stream()), "refnerf_head_bwd")
+    return g_nraw
+
+
+def refnerf_color_fwd(dir_out, spectral, diffuse):
+    m = dir_out.shape[0]
+    rgb = torch.empty((m, 3), dtype=F32, device=_dev(dir_out))
+    L.check(L.lib().lnrf_refnerf_color_fwd(L.ptr(dir_out), L.ptr(spectral), L.ptr(diffuse), m, L.ptr(rgb), L.stream()),
+            "refnerf_color_fwd")
+    return rgb
+
+
+def refnerf_color_bwd(dir_out, spectral, diffuse, g_rgb):
+    m = dir_out.shape[0]
+    dev = _dev(dir_out)
+    g_do = torch.empty((m, 3), dtype=F32, device=dev)
+    g_sp = torch.empty(m, dtype=F32, device=dev)
+    g_df = torch.empty((m, 3), dtype=F32, device=dev)
+    L.check(L.lib().lnrf_refnerf_color_bwd(L.ptr(dir_out), L.ptr(spectral), L.ptr(diffuse), m, L.ptr(g_rgb),
+                                           L.ptr(g_do), L.ptr(g_sp), L.ptr(g_df), L.stream()), "refnerf_color_bwd")
+    return g_do, g_sp, g_df
+
+
 # ---------------------------------------------------------------- optimiser
 
 def adam_step_(p, g, m, v, lr, b1, b2, eps, step: int, grad_scale: float = 1.0):
