@@ -83,10 +83,15 @@ __global__ void hashgrid_fwd_kernel(HashGridDesc d, const float* __restrict__ ta
 // g_tables[level][idx][f] += w * g_enc_t[(2*level+f)*M + m].  Levels whose whole table fits in LDS
 // (G^3 * 8 B <= 64 KiB, i.e. the 16^3 levels that thousands of samples share) are pre-reduced in LDS and
 // flushed once per workgroup; the other levels use fp32 atomics directly.
-__global__ void hashgrid_bwd_kernel(HashGridDesc d, const float* __restrict__ x, int64_t M,
+struct LevelList {
+  int n;
+  int level[kMaxLevels];
+};
+
+__global__ void hashgrid_bwd_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x, int64_t M,
                                     const float* __restrict__ g_enc_t, float* __restrict__ g_tables) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
-  const int level = blockIdx.y;
+  const int level = ll.level[blockIdx.y];
   const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
   float* __restrict__ gtab = g_tables + d.table_offset[level];
   const bool in_lds = !hashed && (int64_t)T * 2 * 4 <= 64 * 1024;
@@ -123,6 +128,51 @@ __global__ void hashgrid_bwd_kernel(HashGridDesc d, const float* __restrict__ x,
       const float v = lds_tab[i];
       if (v != 0.0f) atomicAdd(gtab + i, v);
     }
+  }
+}
+
+// Dense levels whose table does not fit in LDS (G = 32, 64: thousands of samples per entry, so direct
+// atomics contend).  blockIdx.y = 8K-entry slice of the table, blockIdx.z = level in `ll`; every workgroup
+// scans its chunk of points, accumulates only the corners that fall into its slice in LDS, and flushes the
+// slice with contiguous atomics.  The index arithmetic is recomputed once per slice (cheap next to the
+// contended atomics it replaces).
+constexpr int kSliceEntries = 8192;  // 64 KiB of float2
+__global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x, int64_t M,
+                                           const float* __restrict__ g_enc_t, float* __restrict__ g_tables) {
+  extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+  const int level = ll.level[blockIdx.z];
+  const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
+  const unsigned slice0 = blockIdx.y * (unsigned)kSliceEntries;
+  if (slice0 >= (unsigned)T) return;
+  float* __restrict__ gtab = g_tables + d.table_offset[level];
+  for (int i = threadIdx.x; i < kSliceEntries * 2; i += blockDim.x) lds_tab[i] = 0.0f;
+  __syncthreads();
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    const Corner k = locate(p, d, G);
+    const float g0 = g_enc_t[(int64_t)(2 * level) * M + m];
+    const float g1 = g_enc_t[(int64_t)(2 * level + 1) * M + m];
+#pragma unroll
+    for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+      for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+        for (int zo = 0; zo < 2; ++zo) {
+          const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
+          const unsigned rel = idx - slice0;
+          if (rel < (unsigned)kSliceEntries) {
+            const float w = (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) *
+                            (zo ? k.c[2] : 1.0f - k.c[2]);
+            atomicAdd(&lds_tab[2 * rel], w * g0);
+            atomicAdd(&lds_tab[2 * rel + 1], w * g1);
+          }
+        }
+  }
+  __syncthreads();
+  const int n = (T - (int)slice0 < kSliceEntries ? T - (int)slice0 : kSliceEntries) * 2;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = lds_tab[i];
+    if (v != 0.0f) atomicAdd(gtab + 2 * (int64_t)slice0 + i, v);
   }
 }
 
@@ -170,10 +220,34 @@ extern "C" int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x,
   if (m == 0) return LNRF_OK;
   HashGridDesc d;
   memcpy((void*)&d, (const void*)desc, sizeof(d));
-  int64_t bx = (m + 255) / 256;
-  if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)bx, (unsigned)d.n_levels), dim3(256), 64 * 1024,
-                     as_stream(stream), d, x, m, g_enc_t, g_tables);
+  // levels with 8K < entries <= 512K go to the sliced LDS kernel, the rest to the direct kernel
+  LevelList direct, sliced;
+  direct.n = sliced.n = 0;
+  int max_slices = 1;
+  for (int l = 0; l < d.n_levels; ++l) {
+    const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
+    if (slices > 1 && slices <= 64) {
+      sliced.level[sliced.n++] = l;
+      if (slices > max_slices) max_slices = slices;
+    } else {
+      direct.level[direct.n++] = l;
+    }
+  }
+  if (direct.n > 0) {
+    int64_t bx = (m + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)bx, (unsigned)direct.n), dim3(256), 64 * 1024,
+                       as_stream(stream), d, direct, x, m, g_enc_t, g_tables);
+    LNRF_LAUNCH_CHECK();
+  }
+  if (sliced.n > 0) {
+    int64_t bx = 1024 / max_slices;
+    if (bx < 8) bx = 8;
+    const int64_t max_bx = (m + 255) / 256;
+    if (bx > max_bx) bx = max_bx;
+    hipLaunchKernelGGL(hashgrid_bwd_sliced_kernel, dim3((unsigned)bx, (unsigned)max_slices, (unsigned)sliced.n),
+                       dim3(256), 64 * 1024, as_stream(stream), d, sliced, x, m, g_enc_t, g_tables);
+  }
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
