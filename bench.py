@@ -101,6 +101,12 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
 
+    # Libraries (e.g. RCCL's start-up banner) write to the C-level stdout; keep stdout clean for the one
+    # JSON line by pointing fd 1 at stderr until the result is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,7 +115,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -245,7 +251,10 @@ def main():
         )
         if world == 1 and not args.no_cpu_baseline and args.workload == "nerf":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -229,7 +229,7 @@ class TrainLoop:
     def _step(self, key, bmin, bmax, batch):
         self.grad.zero_()
         loss_dict, world = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
-        if world > 1:
+        if _dist() is not None:  # also with a single rank: keeps the collective path exercised
             with _prof.section("allreduce"):
                 parallel.all_reduce_sum_(self.grad)  # RCCL sum over ranks; averaged by grad_scale below
         scale = 1.0 / world
