@@ -62,6 +62,12 @@ int lnrf_ray_aabb_stratified(const float* rays, int64_t ray_stride, int64_t n_ra
                              uint32_t stream_id, int64_t ray_offset, float* t_min, float* t_max,
                              uint8_t* mask, float* ts, lnrf_stream_t stream);
 
+/* CameraView.bare_rays (dataset.py:52-78): all rays of a pinhole view in raster order, rays[H*W, 2, 3]
+ * (device).  origin / axes: (host) 3 floats each; fields of view in radians. */
+int lnrf_camera_rays(const float* origin, const float* x_axis, const float* y_axis, const float* z_axis,
+                     float x_fov, float y_fov, int32_t width, int32_t height, float* rays,
+                     lnrf_stream_t stream);
+
 /* RaySamples.stratified_sampling (render.py:121-143) from given t_min/t_max. */
 int lnrf_stratified(const float* t_min, const float* t_max, int64_t n_rays, int32_t count,
                     const float* u, uint64_t seed, uint32_t stream_id, int64_t ray_offset,

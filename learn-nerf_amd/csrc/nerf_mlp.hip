@@ -205,10 +205,10 @@ __device__ __forceinline__ void chain_layer(RING& ring, Init init, GetB getb, Ep
       constexpr int ks = decltype(k_)::value;
       const bf16x8 a = ring.template next<C0 + o * NK + ks>();
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, getb(k_), acc, 0, 0, 0);
-      // keep the software pipeline the source expresses: one LDS fragment read (for the MFMA
-      // kFragAhead steps later) per MFMA, instead of the scheduler's read-wait-use pairs
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      // Keep the software pipeline the source expresses (one LDS fragment read, for the MFMA kFragAhead
+      // steps later, per MFMA) instead of the scheduler's read-wait-use pairs.  A plain scheduling fence
+      // per step does it; sched_group_barrier gives the same code but costs ~15 min of compile time here.
+      __builtin_amdgcn_sched_barrier(0);
     });
     epi(o_, acc);
   });

@@ -448,6 +448,36 @@ __global__ void bin_edges_kernel(const float* __restrict__ ts, const float* __re
   }
 }
 
+// CameraView.bare_rays (dataset.py:52-78): pixel (px, py) in raster order ->
+// direction = normalize(z + tan(x_fov/2) * lx[px] * x_axis + tan(y_fov/2) * ly[py] * y_axis),
+// lx = linspace(-1, 1, W), ly = linspace(-1, 1, H) (end points inclusive); origin = camera origin.
+struct Camera {
+  float origin[3], x_axis[3], y_axis[3], z_axis[3];
+  float tan_x, tan_y;
+};
+__global__ void camera_rays_kernel(Camera cam, int width, int height, float* __restrict__ rays) {
+  const int64_t total = (int64_t)width * height;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int py = (int)(e / width), px = (int)(e - (int64_t)py * width);
+    const float lx = width > 1 ? -1.0f + 2.0f * (float)px / (float)(width - 1) : -1.0f;
+    const float ly = height > 1 ? -1.0f + 2.0f * (float)py / (float)(height - 1) : -1.0f;
+    float d[3];
+    float nrm = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      d[a] = (cam.tan_x * lx) * cam.x_axis[a] + (cam.tan_y * ly) * cam.y_axis[a] + cam.z_axis[a];
+      nrm += d[a] * d[a];
+    }
+    nrm = sqrtf(nrm);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      rays[e * 6 + a] = cam.origin[a];
+      rays[e * 6 + 3 + a] = d[a] / nrm;
+    }
+  }
+}
+
 }  // namespace lnrf
 
 using namespace lnrf;
@@ -592,6 +622,26 @@ extern "C" int lnrf_bin_edges(const float* ts, const float* t_min, const float* 
   if (n_rays == 0 || t == 0) return LNRF_OK;
   hipLaunchKernelGGL(bin_edges_kernel, dim3(grid_for(n_rays * t, 256)), dim3(256), 0, as_stream(stream), ts,
                      t_min, t_max, n_rays, t, starts, ends);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_camera_rays(const float* origin, const float* x_axis, const float* y_axis, const float* z_axis,
+                                float x_fov, float y_fov, int32_t width, int32_t height, float* rays,
+                                lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(origin && x_axis && y_axis && z_axis && rays, "null pointer");
+  LNRF_CHECK_ARG(width >= 1 && height >= 1, "bad image size");
+  Camera cam;
+  for (int a = 0; a < 3; ++a) {
+    cam.origin[a] = origin[a];
+    cam.x_axis[a] = x_axis[a];
+    cam.y_axis[a] = y_axis[a];
+    cam.z_axis[a] = z_axis[a];
+  }
+  cam.tan_x = tanf(x_fov * 0.5f);
+  cam.tan_y = tanf(y_fov * 0.5f);
+  hipLaunchKernelGGL(camera_rays_kernel, dim3(grid_for((int64_t)width * height, 256)), dim3(256), 0,
+                     as_stream(stream), cam, (int)width, (int)height, rays);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "lnrf_last_error": (c_char_p, []),
     "lnrf_ray_aabb_stratified": (c_int32, [_P, c_int64, c_int64, _F3, _F3, c_float, c_float, c_int32, _P,
                                            c_uint64, c_uint32, c_int64, _P, _P, _P, _P, _P]),
+    "lnrf_camera_rays": (c_int32, [_F3, _F3, _F3, _F3, c_float, c_float, c_int32, c_int32, _P, _P]),
     "lnrf_stratified": (c_int32, [_P, _P, c_int64, c_int32, _P, c_uint64, c_uint32, c_int64, _P, _P]),
     "lnrf_ray_points": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "lnrf_fine_sample": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P,

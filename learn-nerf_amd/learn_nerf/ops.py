@@ -45,6 +45,14 @@ def ray_aabb_stratified(rays, bbox_min: Sequence[float], bbox_max: Sequence[floa
     return t_min, t_max, mask, ts
 
 
+def camera_rays(origin, x_axis, y_axis, z_axis, x_fov: float, y_fov: float, width: int, height: int, device):
+    """CameraView.bare_rays on the GPU -> [H*W, 2, 3]."""
+    rays = torch.empty((width * height, 2, 3), dtype=F32, device=device)
+    L.check(L.lib().lnrf_camera_rays(L.f3(origin), L.f3(x_axis), L.f3(y_axis), L.f3(z_axis), float(x_fov),
+                                     float(y_fov), width, height, L.ptr(rays), L.stream()), "camera_rays")
+    return rays
+
+
 def stratified(t_min, t_max, count: int, u=None, seed: int = 0, stream_id: int = 0, ray_offset: int = 0):
     n = t_min.shape[0]
     ts = torch.empty((n, count), dtype=F32, device=_dev(t_min))

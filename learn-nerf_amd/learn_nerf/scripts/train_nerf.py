@@ -1,9 +1,8 @@
 """
-Train a NeRF model on a scene (reference: learn_nerf/scripts/train_nerf.py).
-
-Same flags, defaults, positional argument, stdout line format (``step {i}: k=v ...``), auto-resume
-and save cadence as the reference; the step itself runs in the HIP kernels.  Additive flags:
---precision {bf16,fp32} and, for multi-GPU runs under torchrun, data-parallel sharding of each batch.
+Training CLI with the command line of the reference's scripts/train_nerf.py (same flag names, defaults,
+positional `data_dir`, `step {i}: k=v ...` log lines, resume-if-checkpoint-exists, periodic save), driving
+the HIP train step.  Extra, additive flags: --precision, --max_steps.  Under torchrun every global batch is
+sharded over the ranks and gradients are all-reduced over RCCL.
 """
 import argparse
 import os
@@ -19,124 +18,126 @@ from learn_nerf.model import ModelBase, NeRFModel
 from learn_nerf.rng import Key
 from learn_nerf.train import TrainLoop
 
+# (flag, type, default, help) — values as in scripts/train_nerf.py:21-55
+TRAIN_FLAGS = (
+    ("--seed", int, None, None),
+    ("--lr", float, 1e-4, None),
+    ("--batch_size", int, 4096, "rays per batch"),
+    ("--test_batch_size", int, None, "rays per test batch"),
+    ("--coarse_samples", int, 64, "samples per coarse ray"),
+    ("--fine_samples", int, 128, "samples per fine ray (not including coarse samples)"),
+    ("--density_penalty", float, None, "penalty coefficient for density at random points"),
+    ("--density_penalty_batch_size", int, 128, "batch size for computing density penalty"),
+    ("--save_interval", int, 1000, None),
+    ("--save_path", str, "nerf.pkl", None),
+    ("--test_data_dir", str, None, None),
+    ("--max_steps", int, None, "(additive) stop, and save, after this many steps"),
+)
 
-def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--seed", type=int, default=None)
-    parser.add_argument("--lr", type=float, default=1e-4)
-    parser.add_argument("--batch_size", type=int, default=4096, help="rays per batch")
-    parser.add_argument("--test_batch_size", type=int, default=None, help="rays per test batch")
-    parser.add_argument("--coarse_samples", type=int, default=64, help="samples per coarse ray")
-    parser.add_argument("--fine_samples", type=int, default=128,
-                        help="samples per fine ray (not including coarse samples)")
-    parser.add_argument("--density_penalty", type=float, default=None,
-                        help="penalty coefficient for density at random points")
-    parser.add_argument("--density_penalty_batch_size", type=int, default=128,
-                        help="batch size for computing density penalty")
-    parser.add_argument("--save_interval", type=int, default=1000)
-    parser.add_argument("--save_path", type=str, default="nerf.pkl")
+
+def add_model_args(parser: argparse.ArgumentParser):
+    """Model selection switches shared with render_nerf.py (scripts/train_nerf.py:136-138)."""
+    for switch in ("--instant_ngp", "--ref_nerf"):
+        parser.add_argument(switch, action="store_true")
+    parser.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
+                        help="(additive) NeRFModel arithmetic: fused bf16 MFMA kernels or exact fp32")
+
+
+def create_model(args: argparse.Namespace, metadata: ModelMetadata) -> Tuple[ModelBase, ModelBase, Dict[str, Any]]:
+    """
+    (coarse, fine, extra TrainLoop kwargs) with the hyper-parameters hard-coded by the reference
+    (scripts/train_nerf.py:141-170): hash grids of 6 / 16 levels, 2^18 entries, grid 2^(4 + i//2),
+    Adam(0.9, 0.99, eps 1e-15) for --instant_ngp; sh_degree 4 for --ref_nerf.
+    """
+    use_ref = bool(getattr(args, "ref_nerf", False))
+    if getattr(args, "instant_ngp", False):
+        from learn_nerf.instant_ngp import InstantNGPModel, InstantNGPRefNERFModel
+
+        factory = partial(InstantNGPRefNERFModel, sh_degree=4) if use_ref else InstantNGPModel
+        box = dict(bbox_min=tuple(metadata.bbox_min), bbox_max=tuple(metadata.bbox_max))
+        pair = [factory(table_sizes=[2 ** 18] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], **box)
+                for levels in (6, 16)]
+        return pair[0], pair[1], dict(adam_eps=1e-15, adam_b1=0.9, adam_b2=0.99)
+    if use_ref:
+        from learn_nerf.ref_nerf import RefNERFModel
+
+        return RefNERFModel(sh_degree=4), RefNERFModel(sh_degree=4), {}
+    precision = getattr(args, "precision", "bf16")
+    return NeRFModel(precision=precision), NeRFModel(precision=precision), {}
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description=__doc__)
+    for flag, typ, default, text in TRAIN_FLAGS:
+        parser.add_argument(flag, type=typ, default=default, help=text)
     parser.add_argument("--one_view", action="store_true")
-    parser.add_argument("--test_data_dir", type=str, default=None)
-    parser.add_argument("--max_steps", type=int, default=None, help="(additive) stop after this many steps")
     add_model_args(parser)
     parser.add_argument("data_dir", type=str)
-    args = parser.parse_args()
+    return parser
 
-    if args.test_batch_size is None:
-        args.test_batch_size = args.batch_size
+
+def _maybe_first_view_only(dataset, one_view: bool):
+    if one_view:
+        dataset.views = dataset.views[:1]
+    return dataset
+
+
+def main():
+    args = build_parser().parse_args()
+    test_bs = args.test_batch_size if args.test_batch_size is not None else args.batch_size
 
     rank, local_rank, world = parallel.init_distributed()
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    log = print if rank == 0 else (lambda *a, **k: None)
+    say = print if rank == 0 else (lambda *a, **k: None)
 
-    log("loading dataset...")
-    data = load_dataset(args.data_dir)
-    if args.one_view:
-        data.views = data.views[:1]
+    say("loading dataset...")
+    data = _maybe_first_view_only(load_dataset(args.data_dir), args.one_view)
+    test_data = None
     if args.test_data_dir is not None:
-        log("loading test dataset...")
-        test_data = load_dataset(args.test_data_dir)
-        if args.one_view:
-            test_data.views = test_data.views[:1]
-    else:
-        test_data = None
+        say("loading test dataset...")
+        test_data = _maybe_first_view_only(load_dataset(args.test_data_dir), args.one_view)
+    bbox = (data.metadata.bbox_min, data.metadata.bbox_max)
 
     seed = args.seed if args.seed is not None else random.randint(0, 2 ** 32 - 1)
-    if world > 1:  # every rank must draw the same batches and initial parameters
-        t = torch.tensor([seed], dtype=torch.int64, device="cuda")
-        torch.distributed.broadcast(t, src=0)
-        seed = int(t.item())
+    if world > 1:  # all ranks must agree on the initial parameters and on the batch order
+        shared = torch.tensor([seed], dtype=torch.int64, device="cuda")
+        torch.distributed.broadcast(shared, src=0)
+        seed = int(shared.item())
     init_key, key = Key(seed).split(2)
 
-    log("creating model and train loop...")
-    coarse, fine, train_kwargs = create_model(args, data.metadata)
+    say("creating model and train loop...")
+    coarse, fine, extra = create_model(args, data.metadata)
     loop = TrainLoop(coarse, fine, init_rng=init_key.seed, lr=args.lr, coarse_ts=args.coarse_samples,
                      fine_ts=args.fine_samples, density_penalty=args.density_penalty,
-                     density_penalty_batch_size=args.density_penalty_batch_size, **train_kwargs)
+                     density_penalty_batch_size=args.density_penalty_batch_size, **extra)
     if os.path.exists(args.save_path):
-        log(f"loading from checkpoint: {args.save_path}")
+        say(f"loading from checkpoint: {args.save_path}")
         loop.load(args.save_path)
-    step_fn = loop.step_fn(data.metadata.bbox_min, data.metadata.bbox_max)
+    step_fn = loop.step_fn(*bbox)
 
-    log("training...")
+    say("training...")
     data_key, test_data_key, key = key.split(3)
-    shuffle_dir = os.path.join(args.data_dir, "shuffled")
-    if test_data:
-        test_shuffle_dir = os.path.join(args.test_data_dir, "shuffled")
-        test_iterator = test_data.iterate_batches(test_shuffle_dir, test_data_key.seed, args.test_batch_size)
-    for i, batch in enumerate(data.iterate_batches(shuffle_dir, data_key.seed, args.batch_size)):
+    test_batches = None
+    if test_data is not None:
+        test_batches = test_data.iterate_batches(os.path.join(args.test_data_dir, "shuffled"), test_data_key.seed,
+                                                 test_bs)
+    batches = data.iterate_batches(os.path.join(args.data_dir, "shuffled"), data_key.seed, args.batch_size)
+    for i, batch in enumerate(batches):
         step_key, test_key, key = key.split(3)
-        shard, offset = parallel.shard_rays(batch, rank, world)
-        if test_data is not None:
-            test_batch = next(test_iterator).to(loop.device)
-            _, tl = loop.losses(test_key, data.metadata.bbox_min, data.metadata.bbox_max, test_batch)
-            test_losses = {f"test_{k}": v for k, v in tl.items()}
-        losses = step_fn(Key(step_key.seed, ray_offset=offset), shard.to(loop.device, non_blocking=True))
-        if test_data is not None:
-            losses.update(test_losses)
-        loss_str = " ".join(f"{k}={float(v):.05}" for k, v in losses.items())
-        log(f"step {i}: {loss_str}")
-        if i and i % args.save_interval == 0 and rank == 0:
+        report = {}
+        if test_batches is not None:  # evaluated before the update, like the reference
+            _, held_out = loop.losses(test_key, *bbox, next(test_batches).to(loop.device))
+            report = {f"test_{name}": value for name, value in held_out.items()}
+        mine, first_ray = parallel.shard_rays(batch, rank, world)
+        losses = step_fn(Key(step_key.seed, ray_offset=first_ray), mine.to(loop.device, non_blocking=True))
+        losses.update(report)
+        say(f"step {i}: " + " ".join(f"{name}={float(value):.05}" for name, value in losses.items()))
+        last = args.max_steps is not None and i + 1 >= args.max_steps
+        if rank == 0 and ((i and i % args.save_interval == 0) or last):
             loop.save(args.save_path)
-        if args.max_steps is not None and i + 1 >= args.max_steps:
-            if rank == 0:
-                loop.save(args.save_path)
+        if last:
             break
-
-
-def add_model_args(parser: argparse.ArgumentParser):
-    parser.add_argument("--instant_ngp", action="store_true")
-    parser.add_argument("--ref_nerf", action="store_true")
-    parser.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
-                        help="(additive) NeRFModel arithmetic: fused bf16 MFMA or exact fp32")
-
-
-def create_model(args: argparse.Namespace, metadata: ModelMetadata) -> Tuple[ModelBase, ModelBase, Dict[str, Any]]:
-    """Model hyper-parameters exactly as scripts/train_nerf.py:141-170."""
-    if args.instant_ngp:
-        from learn_nerf.instant_ngp import InstantNGPModel, InstantNGPRefNERFModel
-
-        if args.ref_nerf:
-            model_cls = partial(InstantNGPRefNERFModel, sh_degree=4)
-        else:
-            model_cls = InstantNGPModel
-        coarse = model_cls(table_sizes=[2 ** 18] * 6, grid_sizes=[2 ** (4 + i // 2) for i in range(6)],
-                           bbox_min=tuple(metadata.bbox_min), bbox_max=tuple(metadata.bbox_max))
-        fine = model_cls(table_sizes=[2 ** 18] * 16, grid_sizes=[2 ** (4 + i // 2) for i in range(16)],
-                         bbox_min=tuple(metadata.bbox_min), bbox_max=tuple(metadata.bbox_max))
-        train_kwargs = dict(adam_eps=1e-15, adam_b1=0.9, adam_b2=0.99)
-    else:
-        if args.ref_nerf:
-            from learn_nerf.ref_nerf import RefNERFModel
-
-            model_cls = partial(RefNERFModel, sh_degree=4)
-        else:
-            model_cls = partial(NeRFModel, precision=getattr(args, "precision", "bf16"))
-        coarse = model_cls()
-        fine = model_cls()
-        train_kwargs = dict()
-    return coarse, fine, train_kwargs
 
 
 if __name__ == "__main__":

@@ -175,3 +175,38 @@ def test_camera_rays_and_json_roundtrip(tmp_path):
     (tmp_path / "metadata.json").write_text(json.dumps({"min": [-1, -1, -1], "max": [1, 1, 1]}))
     md = ModelMetadata.from_json(str(tmp_path / "metadata.json"))
     assert md.bbox_min == (-1, -1, -1) and md.bbox_max == (1, 1, 1)
+
+
+def test_blender_converter_and_loader_roundtrip(tmp_path):
+    """convert_dataset/blender.py semantics (axes :39-41, y_fov :42, bbox :59-60) + optional downscale."""
+    import math
+
+    from PIL import Image
+
+    sys.path.insert(0, os.path.join(ROOT, "learn-nerf_amd", "learn_nerf", "scripts"))
+    import convert_blender
+    from learn_nerf.dataset import load_dataset
+
+    src = tmp_path / "blender"
+    (src / "train").mkdir(parents=True)
+    frames = []
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        img = (rng.random((8, 16, 4)) * 255).astype(np.uint8)
+        Image.fromarray(img, "RGBA").save(src / "train" / f"r_{i}.png")
+        m = np.eye(4)
+        m[:3, 3] = [1.0 + i, 2.0, 3.0]
+        frames.append(dict(file_path=f"./train/r_{i}", transform_matrix=m.tolist()))
+    (src / "transforms_train.json").write_text(json.dumps(dict(camera_angle_x=0.8, frames=frames)))
+    out = tmp_path / "out"
+    assert convert_blender.convert(str(src), str(out), resize=8) == 2
+    ds = load_dataset(str(out))
+    assert ds.metadata.bbox_min == (-1.0, -1.0, -1.0) and len(ds.views) == 2
+    v = ds.views[0]
+    assert v.camera_origin == (1.0, 2.0, 3.0) and v.x_axis == (1.0, 0.0, 0.0)
+    assert v.y_axis == (0.0, -1.0, 0.0) and v.camera_direction == (0.0, 0.0, -1.0)
+    assert abs(v.y_fov - 2 * math.atan(math.tan(0.4) * 8 / 16)) < 1e-12
+    assert v.image().shape == (4, 8, 3)  # downscaled 16x8 -> 8x4
+    assert v.rays().shape == (32, 3, 3)
+    with pytest.raises(FileExistsError):
+        convert_blender.convert(str(src), str(out))
