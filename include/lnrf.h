@@ -183,6 +183,18 @@ int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const
 int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m, const float* g_enc_t,
                       float* g_tables, lnrf_stream_t stream);
 
+/* Input-derivative maps of the encoding, needed when a Ref-NeRF head sits on the hash grid
+ * (InstantNGPRefNERFModel, instant_ngp.py:57-89: normals = -d out[:,0]/dx, ref_nerf.py:38-43):
+ *   jvp:        enc_t-shaped (d enc / d x) u,            u [M,3]
+ *   input_grad: g_x[M,3] = (d enc / d x)^T g_enc
+ *   bwd_dir:    g_tables += d/d tables of < (d enc / d x) u , g_enc >   (second-order term) */
+int lnrf_hashgrid_jvp(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, const float* u,
+                      int64_t m, float* enc_t, lnrf_stream_t stream);
+int lnrf_hashgrid_input_grad(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, int64_t m,
+                             const float* g_enc_t, float* g_x, lnrf_stream_t stream);
+int lnrf_hashgrid_bwd_dir(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
+                          const float* g_enc_t, float* g_tables, lnrf_stream_t stream);
+
 /* ------------------------------------------------------------- Ref-NeRF ---- */
 
 /* Transpose / tangent of d sinusoidal_emb / d x (model.py:65-77), needed by the analytic normals

@@ -28,6 +28,7 @@ struct HashGridDesc {  // mirrors lnrf_hashgrid_desc
 struct Corner {
   unsigned base[3];  // floored cell
   float c[3];        // interpolation fraction (after smoothstep if smooth)
+  float dc[3];       // d c[a] / d x[a] (0 outside the bounding box: the clip has zero slope there)
 };
 
 __device__ __forceinline__ Corner locate(const float x[3], const HashGridDesc& d, int G) {
@@ -40,11 +41,29 @@ __device__ __forceinline__ Corner locate(const float x[3], const HashGridDesc& d
     float fl = floorf(fi);
     fl = fminf(fl, (float)(G - 2));                                           // :150
     float c = fi - fl;                                                        // :152
-    if (d.smooth) c = (c * c) * (3.0f - 2.0f * c);                            // :153-154
+    const float extent = d.bbox_max[a] - d.bbox_min[a];
+    const bool inside = x[a] > d.bbox_min[a] && x[a] < d.bbox_max[a];
+    float slope = (d.smooth ? (float)(G - 2) : (float)(G - 1)) / extent;
+    if (d.smooth) {
+      slope *= 6.0f * c * (1.0f - c);                                         // d/dt of t^2 (3 - 2t)
+      c = (c * c) * (3.0f - 2.0f * c);                                        // :153-154
+    }
     r.base[a] = (unsigned)fl;                                                 // :156
     r.c[a] = c;
+    r.dc[a] = inside ? slope : 0.0f;
   }
   return r;
+}
+
+// trilinear weight of corner (xo, yo, zo) and its derivative along direction u: sum_a u_a dw/dx_a
+__device__ __forceinline__ float corner_weight(const Corner& k, int xo, int yo, int zo) {
+  return (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) * (zo ? k.c[2] : 1.0f - k.c[2]);
+}
+__device__ __forceinline__ void corner_weight_grad(const Corner& k, int xo, int yo, int zo, float g[3]) {
+  const float wx = xo ? k.c[0] : 1.0f - k.c[0], wy = yo ? k.c[1] : 1.0f - k.c[1], wz = zo ? k.c[2] : 1.0f - k.c[2];
+  g[0] = (xo ? k.dc[0] : -k.dc[0]) * wy * wz;
+  g[1] = (yo ? k.dc[1] : -k.dc[1]) * wx * wz;
+  g[2] = (zo ? k.dc[2] : -k.dc[2]) * wx * wy;
 }
 
 __device__ __forceinline__ unsigned entry_index(unsigned cx, unsigned cy, unsigned cz, int G, int T, int hashed) {
@@ -53,8 +72,10 @@ __device__ __forceinline__ unsigned entry_index(unsigned cx, unsigned cy, unsign
 }
 
 // enc_t[(2*level + f) * M + m]
+// u == nullptr: the encoding.  u != nullptr ([M,3]): its directional derivative (d enc / d x) u.
 __global__ void hashgrid_fwd_kernel(HashGridDesc d, const float* __restrict__ tables,
-                                    const float* __restrict__ x, int64_t M, float* __restrict__ enc_t) {
+                                    const float* __restrict__ x, const float* __restrict__ u, int64_t M,
+                                    float* __restrict__ enc_t) {
   const int level = blockIdx.y;
   const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
   const float2* __restrict__ tab = reinterpret_cast<const float2*>(tables + d.table_offset[level]);
@@ -68,8 +89,14 @@ __global__ void hashgrid_fwd_kernel(HashGridDesc d, const float* __restrict__ ta
       for (int yo = 0; yo < 2; ++yo)
 #pragma unroll
         for (int zo = 0; zo < 2; ++zo) {  // instant_ngp.py:160-175: weight = prod(o ? c : 1 - c)
-          const float w = (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) *
-                          (zo ? k.c[2] : 1.0f - k.c[2]);
+          float w;
+          if (u) {
+            float gw[3];
+            corner_weight_grad(k, xo, yo, zo, gw);
+            w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
+          } else {
+            w = corner_weight(k, xo, yo, zo);
+          }
           const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
           const float2 v = tab[idx];
           acc.x += w * v.x;
@@ -88,7 +115,8 @@ struct LevelList {
   int level[kMaxLevels];
 };
 
-__global__ void hashgrid_bwd_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x, int64_t M,
+__global__ void hashgrid_bwd_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x,
+                                    const float* __restrict__ u, int64_t M,
                                     const float* __restrict__ g_enc_t, float* __restrict__ g_tables) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   const int level = ll.level[blockIdx.y];
@@ -110,8 +138,14 @@ __global__ void hashgrid_bwd_kernel(HashGridDesc d, LevelList ll, const float* _
       for (int yo = 0; yo < 2; ++yo)
 #pragma unroll
         for (int zo = 0; zo < 2; ++zo) {
-          const float w = (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) *
-                          (zo ? k.c[2] : 1.0f - k.c[2]);
+          float w;
+          if (u) {
+            float gw[3];
+            corner_weight_grad(k, xo, yo, zo, gw);
+            w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
+          } else {
+            w = corner_weight(k, xo, yo, zo);
+          }
           const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
           if (in_lds) {
             atomicAdd(&lds_tab[2 * idx], w * g0);
@@ -131,13 +165,49 @@ __global__ void hashgrid_bwd_kernel(HashGridDesc d, LevelList ll, const float* _
   }
 }
 
+// g_x[m][a] = sum_levels sum_f g_enc_t[(2l+f)*M + m] * sum_corners (d w / d x_a) table[idx][f]
+// (transpose of d enc / d x applied to g_enc; the analytic normal of the Ref-NeRF head on a hash grid)
+__global__ void hashgrid_input_grad_kernel(HashGridDesc d, const float* __restrict__ tables,
+                                           const float* __restrict__ x, int64_t M,
+                                           const float* __restrict__ g_enc_t, float* __restrict__ g_x) {
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int level = 0; level < d.n_levels; ++level) {
+      const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
+      const float2* __restrict__ tab = reinterpret_cast<const float2*>(tables + d.table_offset[level]);
+      const Corner k = locate(p, d, G);
+      const float g0 = g_enc_t[(int64_t)(2 * level) * M + m];
+      const float g1 = g_enc_t[(int64_t)(2 * level + 1) * M + m];
+#pragma unroll
+      for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+        for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+          for (int zo = 0; zo < 2; ++zo) {
+            float gw[3];
+            corner_weight_grad(k, xo, yo, zo, gw);
+            const float2 v = tab[entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed)];
+            const float s = g0 * v.x + g1 * v.y;
+            acc[0] += gw[0] * s;
+            acc[1] += gw[1] * s;
+            acc[2] += gw[2] * s;
+          }
+    }
+    g_x[m * 3 + 0] = acc[0];
+    g_x[m * 3 + 1] = acc[1];
+    g_x[m * 3 + 2] = acc[2];
+  }
+}
+
 // Dense levels whose table does not fit in LDS (G = 32, 64: thousands of samples per entry, so direct
 // atomics contend).  blockIdx.y = 8K-entry slice of the table, blockIdx.z = level in `ll`; every workgroup
 // scans its chunk of points, accumulates only the corners that fall into its slice in LDS, and flushes the
 // slice with contiguous atomics.  The index arithmetic is recomputed once per slice (cheap next to the
 // contended atomics it replaces).
 constexpr int kSliceEntries = 8192;  // 64 KiB of float2
-__global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x, int64_t M,
+__global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x,
+                                           const float* __restrict__ u, int64_t M,
                                            const float* __restrict__ g_enc_t, float* __restrict__ g_tables) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   const int level = ll.level[blockIdx.z];
@@ -161,8 +231,14 @@ __global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const f
           const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
           const unsigned rel = idx - slice0;
           if (rel < (unsigned)kSliceEntries) {
-            const float w = (xo ? k.c[0] : 1.0f - k.c[0]) * (yo ? k.c[1] : 1.0f - k.c[1]) *
-                            (zo ? k.c[2] : 1.0f - k.c[2]);
+            float w;
+            if (u) {
+              float gw[3];
+              corner_weight_grad(k, xo, yo, zo, gw);
+              w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
+            } else {
+              w = corner_weight(k, xo, yo, zo);
+            }
             atomicAdd(&lds_tab[2 * rel], w * g0);
             atomicAdd(&lds_tab[2 * rel + 1], w * g1);
           }
@@ -196,6 +272,11 @@ static_assert(sizeof(HashGridDesc) == sizeof(lnrf_hashgrid_desc), "descriptor la
 
 extern "C" int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, int64_t m,
                                  float* enc_t, lnrf_stream_t stream) {
+  return lnrf_hashgrid_jvp(desc, tables, x, nullptr, m, enc_t, stream);
+}
+
+extern "C" int lnrf_hashgrid_jvp(const lnrf_hashgrid_desc* desc, const float* tables, const float* x,
+                                 const float* u, int64_t m, float* enc_t, lnrf_stream_t stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   LNRF_CHECK_ARG(tables && x && enc_t, "null pointer");
@@ -206,13 +287,35 @@ extern "C" int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* ta
   int64_t bx = (m + 255) / 256;
   if (bx > 4096) bx = 4096;
   hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)bx, (unsigned)d.n_levels), dim3(256), 0, as_stream(stream),
-                     d, tables, x, m, enc_t);
+                     d, tables, x, u, m, enc_t);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
 
 extern "C" int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m, const float* g_enc_t,
                                  float* g_tables, lnrf_stream_t stream) {
+  return lnrf_hashgrid_bwd_dir(desc, x, nullptr, m, g_enc_t, g_tables, stream);
+}
+
+extern "C" int lnrf_hashgrid_input_grad(const lnrf_hashgrid_desc* desc, const float* tables, const float* x,
+                                        int64_t m, const float* g_enc_t, float* g_x, lnrf_stream_t stream) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  LNRF_CHECK_ARG(tables && x && g_enc_t && g_x, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  HashGridDesc d;
+  memcpy((void*)&d, (const void*)desc, sizeof(d));
+  int64_t bx = (m + 255) / 256;
+  if (bx > 8192) bx = 8192;
+  hipLaunchKernelGGL(hashgrid_input_grad_kernel, dim3((unsigned)bx), dim3(256), 0, as_stream(stream), d, tables, x, m,
+                     g_enc_t, g_x);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_hashgrid_bwd_dir(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
+                                     const float* g_enc_t, float* g_tables, lnrf_stream_t stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   LNRF_CHECK_ARG(x && g_enc_t && g_tables, "null pointer");
@@ -237,7 +340,7 @@ extern "C" int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x,
     int64_t bx = (m + 255) / 256;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)bx, (unsigned)direct.n), dim3(256), 64 * 1024,
-                       as_stream(stream), d, direct, x, m, g_enc_t, g_tables);
+                       as_stream(stream), d, direct, x, u, m, g_enc_t, g_tables);
     LNRF_LAUNCH_CHECK();
   }
   if (sliced.n > 0) {
@@ -246,7 +349,7 @@ extern "C" int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x,
     const int64_t max_bx = (m + 255) / 256;
     if (bx > max_bx) bx = max_bx;
     hipLaunchKernelGGL(hashgrid_bwd_sliced_kernel, dim3((unsigned)bx, (unsigned)max_slices, (unsigned)sliced.n),
-                       dim3(256), 64 * 1024, as_stream(stream), d, sliced, x, m, g_enc_t, g_tables);
+                       dim3(256), 64 * 1024, as_stream(stream), d, sliced, x, u, m, g_enc_t, g_tables);
   }
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;

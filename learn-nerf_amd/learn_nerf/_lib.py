@@ -56,6 +56,9 @@ PROTOTYPES = {
                                 c_int64, c_int32, c_int64, c_int32, _P]),
     "lnrf_hashgrid_fwd": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P]),
     "lnrf_hashgrid_bwd": (c_int32, [POINTER(HashGridDesc), _P, c_int64, _P, _P, _P]),
+    "lnrf_hashgrid_jvp": (c_int32, [POINTER(HashGridDesc), _P, _P, _P, c_int64, _P, _P]),
+    "lnrf_hashgrid_input_grad": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_hashgrid_bwd_dir": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P]),
     "lnrf_sinusoidal_emb_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P]),
     "lnrf_sinusoidal_emb_jvp": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, c_int64, _P]),
     "lnrf_integrated_directional_encoding": (c_int32, [c_int32, _P, _P, c_int64, _P, _P]),

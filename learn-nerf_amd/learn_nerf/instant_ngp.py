@@ -231,13 +231,124 @@ class InstantNGPModel(ModelBase):
 
 @dataclass
 class InstantNGPRefNERFModel(ModelBase):
-    """instant_ngp.py:57-89 (Ref-NeRF head on a smooth hash grid): not built yet."""
+    """
+    A Ref-NeRF head on a smooth multilevel hash table (instant_ngp.py:57-89).  The spatial block is
+    smooth-hash-grid -> Dense(hidden) relu -> Dense(density_dim); its first 9 outputs are the Ref-NeRF heads
+    and the whole vector feeds the directional block together with the IDE and -d.n.  The analytic normal
+    needs d enc / d x (lnrf_hashgrid_input_grad) and, because it is trained through, the second-order terms
+    lnrf_hashgrid_jvp / lnrf_hashgrid_bwd_dir.
+    """
 
     sh_degree: int = 4
     table_sizes: Sequence[int] = None
     grid_sizes: Sequence[int] = None
     bbox_min: Sequence[float] = None
     bbox_max: Sequence[float] = None
+    table_feature_dim: int = 2
+    d_freqs: int = 4  # unused, as in the reference
+    hidden_dim: int = 64
+    density_dim: int = 16
+    density_layers: int = 1
+    color_layers: int = 2
+    tag: str = "ngpref"
 
-    def param_spec(self):
-        raise NotImplementedError("InstantNGPRefNERFModel is not implemented in this build (see DESIGN.md section 7)")
+    def encoding(self) -> MultiresHashTableEncoding:
+        return MultiresHashTableEncoding(self.table_sizes, self.grid_sizes, self.bbox_min, self.bbox_max,
+                                         self.table_feature_dim, True)
+
+    def dense_dims(self) -> List[Tuple[int, int]]:
+        dims, fan = [], len(self.grid_sizes) * self.table_feature_dim
+        for _ in range(self.density_layers):
+            dims.append((fan, self.hidden_dim))
+            fan = self.hidden_dim
+        dims.append((fan, self.density_dim))
+        fan = self.density_dim + self.sh_degree ** 2 + 1
+        for _ in range(self.color_layers):
+            dims.append((fan, self.hidden_dim))
+            fan = self.hidden_dim
+        dims.append((fan, 3))
+        return dims
+
+    param_spec = InstantNGPModel.param_spec
+    init_flat_ = InstantNGPModel.init_flat_
+    _dense_views = InstantNGPModel._dense_views
+
+    def forward_points(self, flat, x, d, save: bool):
+        if self.density_layers != 1:
+            raise NotImplementedError("InstantNGPRefNERFModel: density_layers != 1")
+        enc = self.encoding()
+        desc = enc.desc()
+        tables, W = self._dense_views(flat)
+        m, dev, hd, dd = x.shape[0], flat.device, self.hidden_dim, self.density_dim
+        lf, ne = len(self.grid_sizes) * self.table_feature_dim, self.sh_degree ** 2
+        enc_t = ops.hashgrid_fwd(desc, tables, x)
+        h0 = torch.empty((m, hd), dtype=F32, device=dev)
+        ops.gemm(enc_t, 1, m, W[0][0], hd, 1, h0, hd, m, hd, lf, bias=W[0][1], act=L.ACT_RELU)
+        dir_in = torch.empty((m, dd + ne + 1), dtype=F32, device=dev)
+        ops.dense_fwd(h0, W[1][0], W[1][1], L.ACT_NONE, out=dir_in[:, :dd])
+        # analytic normal: c1 = -e0, c0 = relu'(h0) * (c1 W1^T), g_enc = W0 c0, nraw = (d enc/dx)^T g_enc
+        c1 = torch.zeros((m, dd), dtype=F32, device=dev)
+        c1[:, 0] = -1.0
+        c0 = ops.act_bwd_(ops.dense_bwd_input(c1, W[1][0]), h0, L.ACT_RELU)
+        g_enc_t = torch.empty((lf, m), dtype=F32, device=dev)
+        ops.gemm(W[0][0], hd, 1, c0, 1, hd, g_enc_t, m, lf, m, hd)
+        nraw = ops.hashgrid_input_grad(desc, tables, x, g_enc_t)
+        density, diffuse, spectral, aux2 = ops.refnerf_head_fwd(dir_in, nraw, d, self.sh_degree, dir_in[:, dd:])
+        c = dir_in
+        cacts = []
+        li = 2
+        for _ in range(self.color_layers):
+            c = ops.dense_fwd(c, W[li][0], W[li][1], L.ACT_RELU)
+            cacts.append(c)
+            li += 1
+        dir_out = ops.dense_fwd(c, W[li][0], W[li][1], L.ACT_NONE)
+        rgb = ops.refnerf_color_fwd(dir_out, spectral, diffuse)
+        aux = dict(normal_mse=aux2[:, 0], neg_normal=aux2[:, 1])
+        ctx = None
+        if save:
+            ctx = dict(flat=flat, x=x, d=d, enc_t=enc_t, h0=h0, dir_in=dir_in, c0=c0, c1=c1, g_enc_t=g_enc_t,
+                       nraw=nraw, density=density, diffuse=diffuse, spectral=spectral, cacts=cacts, dir_out=dir_out)
+        return density, rgb, aux, ctx
+
+    def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+        enc = self.encoding()
+        desc = enc.desc()
+        tables, W = self._dense_views(ctx["flat"])
+        g_tables, G = self._dense_views(grad_flat)
+        x, d, h0, dir_in, cacts = ctx["x"], ctx["d"], ctx["h0"], ctx["dir_in"], ctx["cacts"]
+        m, dev, hd, dd = x.shape[0], grad_flat.device, self.hidden_dim, self.density_dim
+        lf = len(self.grid_sizes) * self.table_feature_dim
+        if g_aux is None:
+            g_aux2 = torch.zeros((m, 2), dtype=F32, device=dev)
+        else:
+            g_aux2 = torch.stack([g_aux["normal_mse"].reshape(-1), g_aux["neg_normal"].reshape(-1)], 1).contiguous()
+        g_do, g_sp, g_df = ops.refnerf_color_bwd(ctx["dir_out"], ctx["spectral"], ctx["diffuse"],
+                                                 g_rgb.reshape(-1, 3).contiguous())
+        li = len(W) - 1
+        gy = g_do
+        for i in reversed(range(self.color_layers)):
+            ops.dense_bwd_weight(cacts[i], gy, G[li][0], G[li][1])
+            gy = ops.act_bwd_(ops.dense_bwd_input(gy, W[li][0]), cacts[i], L.ACT_RELU)
+            li -= 1
+        ops.dense_bwd_weight(dir_in, gy, G[li][0], G[li][1])
+        g_dir_in = ops.dense_bwd_input(gy, W[li][0])
+        u = ops.refnerf_head_bwd(dir_in, ctx["nraw"], d, self.sh_degree, g_density.reshape(-1).contiguous(), g_df,
+                                 g_sp, g_dir_in[:, dd:], g_aux2, g_dir_in)
+        # (i) first-order path through Dense_1, Dense_0 and the tables
+        g_out = g_dir_in[:, :dd]
+        ops.dense_bwd_weight(h0, g_out, G[1][0], G[1][1])
+        gy0 = ops.act_bwd_(ops.dense_bwd_input(g_out, W[1][0]), h0, L.ACT_RELU)
+        ops.gemm(ctx["enc_t"], m, 1, gy0, hd, 1, G[0][0], hd, lf, hd, m, mode=2)
+        ops.bias_grad(gy0, G[0][1])
+        g1_t = torch.empty((lf, m), dtype=F32, device=dev)
+        ops.gemm(W[0][0], hd, 1, gy0, 1, hd, g1_t, m, lf, m, hd)
+        ops.hashgrid_bwd(desc, x, g1_t, g_tables)
+        # (ii) second-order path: nraw = J^T g_enc with J = d enc/dx (linear in the tables), g_enc = W0 c0,
+        # c0 = mask(h0) * (c1 W1^T).  Given u = dL/d nraw:
+        ops.hashgrid_bwd_dir(desc, x, u, ctx["g_enc_t"], g_tables)          # d/d tables
+        gbar_t = ops.hashgrid_jvp(desc, tables, x, u)                        # gbar_enc = J u, [L*F, M]
+        ops.gemm(gbar_t, m, 1, ctx["c0"], hd, 1, G[0][0], hd, lf, hd, m, mode=2)  # dW0 += gbar_enc (x) c0
+        cbar0 = torch.empty((m, hd), dtype=F32, device=dev)
+        ops.gemm(gbar_t, 1, m, W[0][0], hd, 1, cbar0, hd, m, hd, lf)         # cbar0 = gbar_enc^T W0
+        tbar0 = ops.act_bwd_(cbar0, h0, L.ACT_RELU)
+        ops.dense_bwd_weight(tbar0, ctx["c1"], G[1][0], None)                # dW1 += tbar0^T c1

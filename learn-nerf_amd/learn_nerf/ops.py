@@ -233,6 +233,36 @@ def hashgrid_fwd(desc, tables: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return enc_t
 
 
+def hashgrid_jvp(desc, tables: torch.Tensor, x: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """(d enc / d x) u in the feature-major layout [L*F, M]"""
+    import ctypes
+
+    m = x.shape[0]
+    out = torch.empty((desc.n_levels * desc.feature_dim, m), dtype=F32, device=_dev(x))
+    L.check(L.lib().lnrf_hashgrid_jvp(ctypes.byref(desc), L.ptr(tables), L.ptr(x), L.ptr(u), m, L.ptr(out),
+                                      L.stream()), "hashgrid_jvp")
+    return out
+
+
+def hashgrid_input_grad(desc, tables: torch.Tensor, x: torch.Tensor, g_enc_t: torch.Tensor) -> torch.Tensor:
+    """(d enc / d x)^T g_enc -> [M, 3]"""
+    import ctypes
+
+    m = x.shape[0]
+    g_x = torch.empty((m, 3), dtype=F32, device=_dev(x))
+    L.check(L.lib().lnrf_hashgrid_input_grad(ctypes.byref(desc), L.ptr(tables), L.ptr(x), m, L.ptr(g_enc_t),
+                                             L.ptr(g_x), L.stream()), "hashgrid_input_grad")
+    return g_x
+
+
+def hashgrid_bwd_dir(desc, x: torch.Tensor, u: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor):
+    import ctypes
+
+    m = x.shape[0]
+    L.check(L.lib().lnrf_hashgrid_bwd_dir(ctypes.byref(desc), L.ptr(x), L.ptr(u), m, L.ptr(g_enc_t),
+                                          L.ptr(g_tables), L.stream()), "hashgrid_bwd_dir")
+
+
 def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor):
     import ctypes
 

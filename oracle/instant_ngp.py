@@ -119,3 +119,61 @@ def ngp_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, table_sizes,
         li += 1
     color = torch.tanh(out @ layers[li][0] + layers[li][1])  # :53
     return density, color, {}
+
+
+def ngp_ref_spec(table_sizes, grid_sizes, feature_dim=2, hidden_dim=64, density_dim=16, density_layers=1,
+                 color_layers=2, sh_degree=4):
+    rows = [level_rows(g, t)[0] for t, g in zip(table_sizes, grid_sizes)]
+    dims, fan = [], len(rows) * feature_dim
+    for _ in range(density_layers):
+        dims.append((fan, hidden_dim))
+        fan = hidden_dim
+    dims.append((fan, density_dim))
+    fan = density_dim + sh_degree * sh_degree + 1
+    for _ in range(color_layers):
+        dims.append((fan, hidden_dim))
+        fan = hidden_dim
+    dims.append((fan, 3))
+    return rows, dims
+
+
+def ngp_ref_nerf_model(flat, x, d, table_sizes, grid_sizes, bbox_min, bbox_max, sh_degree=4, feature_dim=2,
+                       hidden_dim=64, density_dim=16, density_layers=1, color_layers=2):
+    """InstantNGPRefNERFModel (instant_ngp.py:57-89): Ref-NeRF head on a smooth hash grid."""
+    from .ref_nerf import ref_nerf_base
+
+    rows, dims = ngp_ref_spec(table_sizes, grid_sizes, feature_dim, hidden_dim, density_dim, density_layers,
+                              color_layers, sh_degree)
+    off = 0
+    tables = []
+    for r in rows:
+        tables.append(flat[off:off + r * feature_dim].reshape(r, feature_dim))
+        off += r * feature_dim
+    layers = []
+    for i, o in dims:
+        k = flat[off:off + i * o].reshape(i, o)
+        off += i * o
+        layers.append((k, flat[off:off + o]))
+        off += o
+    assert off == flat.numel()
+    bmin = torch.as_tensor(bbox_min, dtype=x.dtype)
+    bmax = torch.as_tensor(bbox_max, dtype=x.dtype)
+
+    def spatial_block(xx):  # instant_ngp.py:72-83 (smooth=True)
+        h = torch.cat([hash_table_encoding(xx, tb, g, t, bmin, bmax, True)
+                       for tb, t, g in zip(tables, table_sizes, grid_sizes)], dim=1)
+        li = 0
+        for _ in range(density_layers):
+            h = torch.relu(h @ layers[li][0] + layers[li][1])
+            li += 1
+        return h @ layers[li][0] + layers[li][1]
+
+    def directional_block(inp):  # instant_ngp.py:85-89
+        li = density_layers + 1
+        h = inp
+        for _ in range(color_layers):
+            h = torch.relu(h @ layers[li][0] + layers[li][1])
+            li += 1
+        return h @ layers[li][0] + layers[li][1]
+
+    return ref_nerf_base(spatial_block, directional_block, x, d, sh_degree)

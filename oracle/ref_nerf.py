@@ -91,9 +91,32 @@ def ref_nerf_layer_dims(input_layers=5, mid_layers=4, hidden_dim=256, color_laye
     return dims
 
 
+def ref_nerf_base(spatial_block, directional_block, x: torch.Tensor, d: torch.Tensor, sh_degree: int):
+    """RefNERFBase.__call__ (ref_nerf.py:35-77) for arbitrary spatial / directional blocks."""
+    xr = x if x.requires_grad else x.clone().requires_grad_(True)
+    out = spatial_block(xr)
+    (real_normal,) = torch.autograd.grad(-out[:, 0].sum(), xr, create_graph=True)  # ref_nerf.py:38-42
+    real_normal = _safe_normalize(real_normal)
+    density = torch.exp(out[:, 0:1])  # :45-48
+    diffuse = torch.sigmoid(out[:, 1:4] - math.log(3))  # :52
+    spectral = torch.sigmoid(out[:, 4:5])
+    roughness = torch.nn.functional.softplus(out[:, 5:6])
+    normal = _safe_normalize(out[:, 6:9])
+    reflection = d - 2 * normal * (d * normal).sum(dim=-1, keepdim=True)  # :59
+    enc = integrated_directional_encoding(sh_degree, reflection, roughness)
+    normal_dot = (-d * normal).sum(dim=-1, keepdim=True)
+    dir_input = torch.cat([out, enc, normal_dot], dim=1)  # :63 (the WHOLE spatial_out, not just the bottleneck)
+    dir_output = directional_block(dir_input)
+    spectral_color = torch.sigmoid(dir_output)
+    full_color = linear_rgb_to_srgb(_leaky_clip(spectral_color * spectral + diffuse)) * 2 - 1  # :67-71
+    aux = dict(normal_mse=((normal - real_normal) ** 2).sum(dim=-1),  # :72-75
+               neg_normal=torch.clamp((normal * d).sum(dim=-1), min=0.0) ** 2)
+    return density, full_color, aux
+
+
 def ref_nerf_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, sh_degree=4, input_layers=5, mid_layers=4,
                    hidden_dim=256, color_layer_dim=128, x_freqs=10):
-    """RefNERFBase.__call__ (ref_nerf.py:35-77) with RefNERFModel's blocks -> (density, rgb, aux dict)."""
+    """RefNERFModel (ref_nerf.py:80-107) -> (density, rgb, aux dict)."""
     dims = ref_nerf_layer_dims(input_layers, mid_layers, hidden_dim, color_layer_dim, x_freqs, sh_degree)
     layers = unflatten(flat, dims)
 
@@ -112,24 +135,9 @@ def ref_nerf_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, sh_degr
             li += 1
         return z
 
-    xr = x if x.requires_grad else x.clone().requires_grad_(True)
-    out = spatial_block(xr)
-    (real_normal,) = torch.autograd.grad(-out[:, 0].sum(), xr, create_graph=True)  # ref_nerf.py:38-42
-    real_normal = _safe_normalize(real_normal)
-    density = torch.exp(out[:, 0:1])  # :45-48
-    diffuse = torch.sigmoid(out[:, 1:4] - math.log(3))  # :52
-    spectral = torch.sigmoid(out[:, 4:5])
-    roughness = torch.nn.functional.softplus(out[:, 5:6])
-    normal = _safe_normalize(out[:, 6:9])
-    reflection = d - 2 * normal * (d * normal).sum(dim=-1, keepdim=True)  # :59
-    enc = integrated_directional_encoding(sh_degree, reflection, roughness)
-    normal_dot = (-d * normal).sum(dim=-1, keepdim=True)
-    dir_input = torch.cat([out, enc, normal_dot], dim=1)  # :63 (the WHOLE spatial_out, not just the bottleneck)
-    li = input_layers + mid_layers
-    h = torch.relu(dir_input @ layers[li][0] + layers[li][1])  # ref_nerf.py:105-107
-    dir_output = h @ layers[li + 1][0] + layers[li + 1][1]
-    spectral_color = torch.sigmoid(dir_output)
-    full_color = linear_rgb_to_srgb(_leaky_clip(spectral_color * spectral + diffuse)) * 2 - 1  # :67-71
-    aux = dict(normal_mse=((normal - real_normal) ** 2).sum(dim=-1),  # :72-75
-               neg_normal=torch.clamp((normal * d).sum(dim=-1), min=0.0) ** 2)
-    return density, full_color, aux
+    def directional_block(inp):  # ref_nerf.py:105-107
+        li = input_layers + mid_layers
+        h = torch.relu(inp @ layers[li][0] + layers[li][1])
+        return h @ layers[li + 1][0] + layers[li + 1][1]
+
+    return ref_nerf_base(spatial_block, directional_block, x, d, sh_degree)

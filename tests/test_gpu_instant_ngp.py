@@ -151,3 +151,44 @@ def test_ngp_train_step_matches_oracle():
     # entries with (numerically) zero gradient move by +-lr under eps = 1e-15 depending on rounding noise
     big = ref_grad.abs() > 1e-9
     assert upd[big].max().item() < 1e-4
+
+
+@pytest.mark.parametrize("levels,table", [(4, 2 ** 10), (8, 2 ** 12)])
+def test_ngp_ref_nerf_forward_backward(levels, table):
+    """InstantNGPRefNERFModel (instant_ngp.py:57-89) incl. the second-order term, vs float64 autograd."""
+    from learn_nerf.instant_ngp import InstantNGPRefNERFModel
+
+    grids = [2 ** (3 + i // 2) for i in range(levels)]
+    model = InstantNGPRefNERFModel(sh_degree=4, table_sizes=[table] * levels, grid_sizes=grids, bbox_min=BMIN,
+                                   bbox_max=BMAX)
+    params = model.init(dict(params=5))["params"]
+    flat = model.flat(params)
+    nt = model.encoding().num_table_floats()
+    gen = torch.Generator().manual_seed(6)
+    flat[:nt] = ((torch.rand(nt, generator=gen) * 2 - 1) * 0.5).cuda()
+    m = 1200
+    lo, hi = torch.tensor(BMIN), torch.tensor(BMAX)
+    x = (torch.rand(m, 3, generator=gen) * (hi - lo) * 0.98 + lo + 0.01 * (hi - lo)).float().contiguous()
+    d = torch.randn(m, 3, generator=gen)
+    d = (d / d.norm(dim=-1, keepdim=True)).float().contiguous()
+    assert model.num_params() == nt + sum(i * o + o for i, o in ON.ngp_ref_spec(model.table_sizes, grids)[1])
+    dens, rgb, aux = model.apply(dict(params=params), x.cuda(), d.cuda())
+    f64 = flat.cpu().double().requires_grad_(True)
+    rd, rr, raux = ON.ngp_ref_nerf_model(f64, x.double(), d.double(), model.table_sizes, grids, BMIN, BMAX)
+    assert (rgb.cpu().double() - rr).abs().max().item() < 1e-4
+    assert ((dens.cpu().double() - rd).abs() / (1 + rd.abs())).max().item() < 1e-4
+    for k in aux:
+        assert (aux[k].cpu().double() - raux[k]).abs().max().item() < 5e-3, k
+    g_d = torch.randn(m, generator=gen).float()
+    g_c = torch.randn(m, 3, generator=gen).float()
+    g_a = {"normal_mse": torch.rand(m, generator=gen).float(), "neg_normal": torch.rand(m, generator=gen).float()}
+    loss = (rd[:, 0] * g_d.double()).sum() + (rr * g_c.double()).sum() + sum((raux[k] * g_a[k].double()).sum() for k in g_a)
+    (g_ref,) = torch.autograd.grad(loss, f64)
+    _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+    grad = torch.zeros_like(flat)
+    model.backward(ctx, g_d.cuda(), g_c.cuda(), {k: v.cuda() for k, v in g_a.items()}, grad)
+    got = grad.cpu().double()
+    for name, a, b in (("tables", got[:nt], g_ref[:nt]), ("mlp", got[nt:], g_ref[nt:])):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"ngp-ref L={levels} {name}: rel L2 err {rel:.2e}")
+        assert rel < 5e-3, (name, rel)
