@@ -184,6 +184,14 @@ __device__ __forceinline__ bf16x8 masked_frag(const f32x16& acc, unsigned bits, 
   return f;
 }
 
+// the activation / gradient dumps are written once and read by a later kernel: non-temporal stores keep
+// them from displacing the L2-resident weight stream
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(char* p, uint4 v) {
+  u32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+}
+
 struct DumpAddr {
   char* base;       // [slot][tile][1 KiB]
   int64_t n_tiles;  // tiles in the buffer
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 
   DumpAddr dump{save, n_tiles, tile, c, h};
   auto save_frag = [&](int slot, const bf16x8& f) {
-    if (SAVE && tile_ok) *reinterpret_cast<uint4*>(dump.at(slot)) = frag_to_bits(f);
+    if (SAVE && tile_ok) stream_store(dump.at(slot), frag_to_bits(f));
   };
   if (SAVE) {
     static_for<4>([&](auto i) { save_frag(kSaveXin + decltype(i)::value, xe[decltype(i)::value]); });
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
 
   DumpAddr gd{gdump, n_tiles, tile, c, h};
   auto dump_frag = [&](int slot, const bf16x8& f) {
-    if (tile_ok) *reinterpret_cast<uint4*>(gd.at(slot)) = frag_to_bits(f);
+    if (tile_ok) stream_store(gd.at(slot), frag_to_bits(f));
   };
 
   bf16x8 a0[16], a1[16];
@@ -593,8 +601,9 @@ struct WgStage {
         int f = wave + kWaves * q;
         if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
         const char* src = f < NXF ? x_src + (int64_t)f * slot_stride : y_src + (int64_t)(f - NXF) * slot_stride;
-        const uint4 v = *reinterpret_cast<const uint4*>(src + st * kFragBytes);
-        rr[u][q] = make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
+        // read-once operands: non-temporal loads leave L2 / Infinity Cache to data that is reused
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + st * kFragBytes));
+        rr[u][q] = make_uint4(v[0] & keep, v[1] & keep, v[2] & keep, v[3] & keep);
       }
     }
   }
