@@ -60,26 +60,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const bool a_r_fast = (sa_r == 1);
   const bool b_j_fast = (sb_j == 1);
 
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += RC) {
-    // stage A tile [64][16]
+  // software pipeline: the global loads of reduction chunk r0 + RC are in registers while chunk r0 is
+  // multiplied out of LDS (the loop was latency-bound on one global round trip per 16-deep chunk before)
+  constexpr int NA = (TI * RC) / 256, NB = (RC * TJ) / 256;
+  float ra[NA], rb[NB];
+  auto fetch = [&](int64_t r0) {
 #pragma unroll
-    for (int q = 0; q < (TI * RC) / 256; ++q) {
+    for (int q = 0; q < NA; ++q) {
       const int e = q * 256 + tid;
       int ii, rr;
       if (a_r_fast) { rr = e % RC; ii = e / RC; } else { ii = e % TI; rr = e / TI; }
       const int64_t gi = i0 + ii, gr = r0 + rr;
-      As[ii][rr] = (gi < I && gr < r_end) ? a[gi * sa_i + gr * sa_r] : 0.0f;
+      ra[q] = (gi < I && gr < r_end) ? a[gi * sa_i + gr * sa_r] : 0.0f;
     }
 #pragma unroll
-    for (int q = 0; q < (RC * TJ) / 256; ++q) {
+    for (int q = 0; q < NB; ++q) {
       const int e = q * 256 + tid;
       int jj, rr;
       if (b_j_fast) { jj = e % TJ; rr = e / TJ; } else { rr = e % RC; jj = e / RC; }
       const int gj = j0 + jj;
       const int64_t gr = r0 + rr;
-      Bs[rr][jj] = (gj < J && gr < r_end) ? b[gr * sb_r + (int64_t)gj * sb_j] : 0.0f;
+      rb[q] = (gj < J && gr < r_end) ? b[gr * sb_r + (int64_t)gj * sb_j] : 0.0f;
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int e = q * 256 + tid;
+      int ii, rr;
+      if (a_r_fast) { rr = e % RC; ii = e / RC; } else { ii = e % TI; rr = e / TI; }
+      As[ii][rr] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int e = q * 256 + tid;
+      int jj, rr;
+      if (b_j_fast) { jj = e % TJ; rr = e / TJ; } else { rr = e % RC; jj = e / RC; }
+      Bs[rr][jj] = rb[q];
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += RC) {
+    stage();
     __syncthreads();
+    if (r0 + RC < r_end) fetch(r0 + RC);
 #pragma unroll
     for (int kk = 0; kk < RC / 2; ++kk) {
       const float av = As[wr * 32 + (lane & 31)][kk * 2 + (lane >> 5)];
@@ -212,6 +236,7 @@ extern "C" int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* g
     // gw[kk][j] += sum_m x[m][kk] * gy[m][j]: A(i=kk, r=m) = x[m*ldx + kk]
     const int tiles = ((k + TI - 1) / TI) * ((n + TJ - 1) / TJ);
     int splits = (int)((2048 + tiles - 1) / tiles);
+    if (splits > 512) splits = 512;  // bounds the atomic adders per output element
     const int64_t max_splits = (m + 255) / 256;
     if (splits > max_splits) splits = (int)max_splits;
     int rc = launch_gemm(x, 1, ldx, gy, ldgy, 1, gw, n, nullptr, 0, 2, k, n, m, splits, as_stream(stream));
@@ -251,6 +276,7 @@ extern "C" int lnrf_gemm_f32(const float* a, int64_t sa_i, int64_t sa_r, const f
   if (mode == 2 && splits <= 0) {
     const int64_t tiles = ((i_rows + TI - 1) / TI) * ((j_cols + TJ - 1) / TJ);
     splits = (int)((2048 + tiles - 1) / (tiles > 0 ? tiles : 1));
+    if (splits > 512) splits = 512;
     const int64_t max_splits = (r_depth + 255) / 256;
     if (splits > max_splits) splits = (int)max_splits;
   }
