@@ -183,6 +183,15 @@ int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const
 int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m, const float* g_enc_t,
                       float* g_tables, lnrf_stream_t stream);
 
+/* Same scatter with caller-provided scratch (lnrf_hashgrid_bwd_scratch_bytes): hashed levels are reduced
+ * without global float atomics (bin by 8K-entry table slice, then one workgroup per bucket accumulates in
+ * LDS).  u == NULL: value weights (first-order gradient); u [M,3]: derivative weights (see bwd_dir).
+ * scratch == NULL falls back to the LDS-sliced / atomic kernels. */
+int64_t lnrf_hashgrid_bwd_scratch_bytes(const lnrf_hashgrid_desc* desc, int64_t m);
+int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
+                               const float* g_enc_t, float* g_tables, void* scratch, int64_t scratch_bytes,
+                               lnrf_stream_t stream);
+
 /* Input-derivative maps of the encoding, needed when a Ref-NeRF head sits on the hash grid
  * (InstantNGPRefNERFModel, instant_ngp.py:57-89: normals = -d out[:,0]/dx, ref_nerf.py:38-43):
  *   jvp:        enc_t-shaped (d enc / d x) u,            u [M,3]

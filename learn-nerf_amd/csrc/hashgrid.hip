@@ -252,6 +252,127 @@ __global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Bucketed scatter for the hashed levels (every sample touches 8 effectively random entries, so neither
+// LDS pre-reduction per workgroup nor memory-side atomics are efficient).  Pass A bins the 8 (entry,
+// w*g0, w*g1) contributions of every sample by 8K-entry table slice: a workgroup counts its chunk per slice
+// in LDS, reserves room in each slice's global bucket with ONE atomic per (workgroup, slice), and writes its
+// tuples there.  Pass B gives every (level, slice) bucket to exactly one workgroup, which accumulates the
+// bucket in LDS and adds the slice to the gradient table with plain read-modify-write: no global float atomics.
+// Buckets are sized 1.25x the mean (the hash spreads samples evenly); overflowing tuples fall back to atomics.
+struct BucketTuple {
+  unsigned rel;  // entry index within the slice
+  float v0, v1;
+};
+constexpr int kBinChunk = 2048;  // samples per binning workgroup
+constexpr int kMaxSlices = 128;  // table <= 1M entries
+
+struct BucketPlan {
+  int n;                 // bucketed levels
+  int level[kMaxLevels];
+  int slices[kMaxLevels];
+  long long tuple_off[kMaxLevels];   // first tuple of the level's buckets
+  long long cursor_off[kMaxLevels];  // first cursor of the level
+  long long cap;                     // tuples per bucket (same for all: slices differ only via table size)
+};
+
+__global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float* __restrict__ x,
+                                    const float* __restrict__ u, int64_t M, const float* __restrict__ g_enc_t,
+                                    BucketTuple* __restrict__ tuples, unsigned* __restrict__ cursors,
+                                    float* __restrict__ g_tables) {
+  __shared__ unsigned s_count[kMaxSlices];
+  __shared__ unsigned s_base[kMaxSlices];
+  const int li = blockIdx.y;
+  const int level = plan.level[li];
+  const int S = plan.slices[li];
+  const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
+  BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li];
+  unsigned* __restrict__ cur = cursors + plan.cursor_off[li];
+  const long long cap = plan.cap;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) s_count[i] = 0u;
+  __syncthreads();
+  const int64_t m0 = (int64_t)blockIdx.x * kBinChunk;
+  const int64_t m1 = m0 + kBinChunk < M ? m0 + kBinChunk : M;
+  // pass 1: count per slice
+  for (int64_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
+    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    const Corner k = locate(p, d, G);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned idx = entry_index(k.base[0] + (c >> 2), k.base[1] + ((c >> 1) & 1), k.base[2] + (c & 1), G, T, hashed);
+      atomicAdd(&s_count[idx / kSliceEntries], 1u);
+    }
+  }
+  __syncthreads();
+  // reserve room in the global buckets; s_count becomes the running local offset
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    s_base[i] = s_count[i] ? atomicAdd(&cur[i], s_count[i]) : 0u;
+    s_count[i] = 0u;
+  }
+  __syncthreads();
+  // pass 2: write the tuples
+  for (int64_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
+    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    const Corner k = locate(p, d, G);
+    const float g0 = g_enc_t[(int64_t)(2 * level) * M + m];
+    const float g1 = g_enc_t[(int64_t)(2 * level + 1) * M + m];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int xo = c >> 2, yo = (c >> 1) & 1, zo = c & 1;
+      float w;
+      if (u) {
+        float gw[3];
+        corner_weight_grad(k, xo, yo, zo, gw);
+        w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
+      } else {
+        w = corner_weight(k, xo, yo, zo);
+      }
+      const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
+      const unsigned b = idx / kSliceEntries;
+      const long long pos = (long long)s_base[b] + atomicAdd(&s_count[b], 1u);
+      if (pos < cap) {
+        BucketTuple t;
+        t.rel = idx - b * kSliceEntries;
+        t.v0 = w * g0;
+        t.v1 = w * g1;
+        tup[(long long)b * cap + pos] = t;
+      } else {  // bucket full: rare, stay correct
+        float* gt = g_tables + d.table_offset[level] + 2 * (int64_t)idx;
+        atomicAdd(gt, w * g0);
+        atomicAdd(gt + 1, w * g1);
+      }
+    }
+  }
+}
+
+__global__ void hashgrid_reduce_kernel(HashGridDesc d, BucketPlan plan, const BucketTuple* __restrict__ tuples,
+                                       const unsigned* __restrict__ cursors, float* __restrict__ g_tables) {
+  extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+  const int li = blockIdx.y;
+  const int level = plan.level[li];
+  const int b = blockIdx.x;
+  if (b >= plan.slices[li]) return;
+  const int T = d.table_size[level];
+  for (int i = threadIdx.x; i < kSliceEntries * 2; i += blockDim.x) lds_tab[i] = 0.0f;
+  __syncthreads();
+  long long count = cursors[plan.cursor_off[li] + b];
+  if (count > plan.cap) count = plan.cap;
+  const BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li] + (long long)b * plan.cap;
+  for (long long i = threadIdx.x; i < count; i += blockDim.x) {
+    const BucketTuple t = tup[i];
+    atomicAdd(&lds_tab[2 * t.rel], t.v0);
+    atomicAdd(&lds_tab[2 * t.rel + 1], t.v1);
+  }
+  __syncthreads();
+  const long long slice0 = (long long)b * kSliceEntries;
+  const int n = (int)((T - slice0 < kSliceEntries ? T - slice0 : kSliceEntries) * 2);
+  float* __restrict__ gt = g_tables + d.table_offset[level] + 2 * slice0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = lds_tab[i];
+    if (v != 0.0f) gt[i] += v;  // this workgroup is the only writer of the slice in this launch
+  }
+}
+
 }  // namespace lnrf
 
 using namespace lnrf;
@@ -314,8 +435,55 @@ extern "C" int lnrf_hashgrid_input_grad(const lnrf_hashgrid_desc* desc, const fl
   return LNRF_OK;
 }
 
+static bool level_is_bucketed(const HashGridDesc& d, int l) {
+  const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
+  return d.hashed[l] && slices >= 16 && slices <= kMaxSlices;
+}
+static BucketPlan make_plan(const HashGridDesc& d, int64_t m, int64_t* tuple_total, int64_t* cursor_total) {
+  BucketPlan p;
+  p.n = 0;
+  int64_t toff = 0, coff = 0;
+  int min_slices = kMaxSlices;
+  for (int l = 0; l < d.n_levels; ++l)
+    if (level_is_bucketed(d, l)) {
+      const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
+      if (slices < min_slices) min_slices = slices;
+    }
+  // one capacity for all buckets: 1.25x the mean of the level with the fewest slices, plus slack
+  p.cap = (long long)((double)m * 8.0 / (double)min_slices * 1.25) + 4096;
+  for (int l = 0; l < d.n_levels; ++l) {
+    if (!level_is_bucketed(d, l)) continue;
+    const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
+    p.level[p.n] = l;
+    p.slices[p.n] = slices;
+    p.tuple_off[p.n] = toff;
+    p.cursor_off[p.n] = coff;
+    toff += (int64_t)slices * p.cap;
+    coff += slices;
+    ++p.n;
+  }
+  *tuple_total = toff;
+  *cursor_total = coff;
+  return p;
+}
+
+extern "C" int64_t lnrf_hashgrid_bwd_scratch_bytes(const lnrf_hashgrid_desc* desc, int64_t m) {
+  if (check_desc(desc)) return -1;
+  HashGridDesc d;
+  memcpy((void*)&d, (const void*)desc, sizeof(d));
+  int64_t tuples = 0, cursors = 0;
+  make_plan(d, m, &tuples, &cursors);
+  return ((cursors * 4 + 255) / 256) * 256 + tuples * (int64_t)sizeof(BucketTuple);
+}
+
 extern "C" int lnrf_hashgrid_bwd_dir(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
                                      const float* g_enc_t, float* g_tables, lnrf_stream_t stream) {
+  return lnrf_hashgrid_bwd_bucketed(desc, x, u, m, g_enc_t, g_tables, nullptr, 0, stream);
+}
+
+extern "C" int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
+                                          const float* g_enc_t, float* g_tables, void* scratch,
+                                          int64_t scratch_bytes, lnrf_stream_t stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   LNRF_CHECK_ARG(x && g_enc_t && g_tables, "null pointer");
@@ -323,11 +491,33 @@ extern "C" int lnrf_hashgrid_bwd_dir(const lnrf_hashgrid_desc* desc, const float
   if (m == 0) return LNRF_OK;
   HashGridDesc d;
   memcpy((void*)&d, (const void*)desc, sizeof(d));
+  // hashed levels with >= 16 slices go to the bucketed path when the caller provides scratch memory
+  int64_t tuple_total = 0, cursor_total = 0;
+  const BucketPlan plan = make_plan(d, m, &tuple_total, &cursor_total);
+  const int64_t cursor_bytes = ((cursor_total * 4 + 255) / 256) * 256;
+  const bool use_buckets = scratch && plan.n > 0 &&
+                           scratch_bytes >= cursor_bytes + tuple_total * (int64_t)sizeof(BucketTuple);
+  if (use_buckets) {
+    unsigned* cursors = reinterpret_cast<unsigned*>(scratch);
+    BucketTuple* tuples = reinterpret_cast<BucketTuple*>(reinterpret_cast<char*>(scratch) + cursor_bytes);
+    hipError_t e = hipMemsetAsync(cursors, 0, (size_t)cursor_bytes, as_stream(stream));
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(bucket cursors)");
+    const unsigned chunks = (unsigned)((m + kBinChunk - 1) / kBinChunk);
+    hipLaunchKernelGGL(hashgrid_bin_kernel, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d, plan, x,
+                       u, m, g_enc_t, tuples, cursors, g_tables);
+    LNRF_LAUNCH_CHECK();
+    int max_s = 0;
+    for (int i = 0; i < plan.n; ++i) max_s = plan.slices[i] > max_s ? plan.slices[i] : max_s;
+    hipLaunchKernelGGL(hashgrid_reduce_kernel, dim3((unsigned)max_s, (unsigned)plan.n), dim3(256), 64 * 1024,
+                       as_stream(stream), d, plan, tuples, cursors, g_tables);
+    LNRF_LAUNCH_CHECK();
+  }
   // levels with 8K < entries <= 512K go to the sliced LDS kernel, the rest to the direct kernel
   LevelList direct, sliced;
   direct.n = sliced.n = 0;
   int max_slices = 1;
   for (int l = 0; l < d.n_levels; ++l) {
+    if (use_buckets && level_is_bucketed(d, l)) continue;
     const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
     if (slices > 1 && slices <= 64) {
       sliced.level[sliced.n++] = l;

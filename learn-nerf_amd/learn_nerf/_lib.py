@@ -56,6 +56,8 @@ PROTOTYPES = {
                                 c_int64, c_int32, c_int64, c_int32, _P]),
     "lnrf_hashgrid_fwd": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P]),
     "lnrf_hashgrid_bwd": (c_int32, [POINTER(HashGridDesc), _P, c_int64, _P, _P, _P]),
+    "lnrf_hashgrid_bwd_scratch_bytes": (c_int64, [POINTER(HashGridDesc), c_int64]),
+    "lnrf_hashgrid_bwd_bucketed": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "lnrf_hashgrid_jvp": (c_int32, [POINTER(HashGridDesc), _P, _P, _P, c_int64, _P, _P]),
     "lnrf_hashgrid_input_grad": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P]),
     "lnrf_hashgrid_bwd_dir": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P]),

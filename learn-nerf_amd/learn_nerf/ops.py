@@ -258,17 +258,19 @@ def hashgrid_input_grad(desc, tables: torch.Tensor, x: torch.Tensor, g_enc_t: to
 def hashgrid_bwd_dir(desc, x: torch.Tensor, u: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor):
     import ctypes
 
-    m = x.shape[0]
-    L.check(L.lib().lnrf_hashgrid_bwd_dir(ctypes.byref(desc), L.ptr(x), L.ptr(u), m, L.ptr(g_enc_t),
-                                          L.ptr(g_tables), L.stream()), "hashgrid_bwd_dir")
+    hashgrid_bwd(desc, x, g_enc_t, g_tables, u=u)
 
 
-def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor):
+def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor, u=None):
+    """g_tables += scatter(g_enc_t); hashed levels go through the bucketed (atomic-free) path."""
     import ctypes
 
     m = x.shape[0]
-    L.check(L.lib().lnrf_hashgrid_bwd(ctypes.byref(desc), L.ptr(x), m, L.ptr(g_enc_t), L.ptr(g_tables), L.stream()),
-            "hashgrid_bwd")
+    nbytes = L.lib().lnrf_hashgrid_bwd_scratch_bytes(ctypes.byref(desc), m)
+    scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=_dev(x))
+    L.check(L.lib().lnrf_hashgrid_bwd_bucketed(ctypes.byref(desc), L.ptr(x), L.ptr(u), m, L.ptr(g_enc_t),
+                                               L.ptr(g_tables), L.ptr(scratch, torch.uint8), int(nbytes), L.stream()),
+            "hashgrid_bwd_bucketed")
 
 
 # ---------------------------------------------------------------- Ref-NeRF pieces
