@@ -249,6 +249,24 @@ def main():
             kernels=fams,
             losses={k: round(float(v), 5) for k, v in log.items()},
         )
+        if args.workload == "nerf" and args.precision == "bf16":
+            # the same fused MLP kernel without the activation dumps (what render_nerf.py runs): compute-bound
+            from learn_nerf import ops as _ops
+
+            _, _, _, ts_c = _ops.ray_aabb_stratified(batch, BBOX_MIN, BBOX_MAX, COARSE + FINE, seed=1)
+            c_flat = loop._slices(loop.flat)[1]
+            for _ in range(3):
+                loop.fine.forward_rays(c_flat, batch, ts_c, save=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                loop.fine.forward_rays(c_flat, batch, ts_c, save=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            tf = m_f * FLOP_FWD_PER_EVAL / (ms * 1e-3) / 1e12
+            out["inference_mlp"] = dict(ms=round(ms, 4), tflops=round(tf, 1), frac_of_mfma_peak=round(tf / 2500.0, 4),
+                                        note="fine-pass NeRFModel forward, no activation save (render path)")
         if world == 1 and not args.no_cpu_baseline and args.workload == "nerf":
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -495,6 +495,7 @@ extern "C" int lnrf_ray_aabb_stratified(const float* rays, int64_t ray_stride, i
                                         const float* u, uint64_t seed, uint32_t stream_id,
                                         int64_t ray_offset, float* t_min, float* t_max,
                                         uint8_t* mask, float* ts, lnrf_stream_t stream) {
+  if (n_rays == 0) return LNRF_OK;
   LNRF_CHECK_ARG(rays && bbox_min && bbox_max, "null rays/bbox");
   LNRF_CHECK_ARG(n_rays >= 0 && count >= 0 && ray_stride >= 6, "bad sizes");
   LNRF_CHECK_ARG(count == 0 || ts, "ts is NULL with count > 0");
@@ -515,6 +516,7 @@ extern "C" int lnrf_ray_aabb_stratified(const float* rays, int64_t ray_stride, i
 extern "C" int lnrf_stratified(const float* t_min, const float* t_max, int64_t n_rays,
                                int32_t count, const float* u, uint64_t seed, uint32_t stream_id,
                                int64_t ray_offset, float* ts, lnrf_stream_t stream) {
+  if (n_rays == 0 || count == 0) return LNRF_OK;
   LNRF_CHECK_ARG(t_min && t_max, "null t range");
   LNRF_CHECK_ARG(n_rays >= 0 && count >= 0, "bad sizes");
   if (n_rays == 0 || count == 0) return LNRF_OK;
@@ -528,6 +530,7 @@ extern "C" int lnrf_stratified(const float* t_min, const float* t_max, int64_t n
 extern "C" int lnrf_ray_points(const float* rays, int64_t ray_stride, const float* ts,
                                int64_t n_rays, int32_t t, float* points, float* dirs,
                                lnrf_stream_t stream) {
+  if (n_rays == 0 || t == 0) return LNRF_OK;
   LNRF_CHECK_ARG(rays && ts, "null rays/ts");
   LNRF_CHECK_ARG(n_rays >= 0 && t >= 0 && ray_stride >= 6, "bad sizes");
   if (n_rays == 0 || t == 0) return LNRF_OK;
@@ -540,6 +543,7 @@ extern "C" int lnrf_ray_points(const float* rays, int64_t ray_stride, const floa
 extern "C" int lnrf_termination_probs(const float* ts, const float* t_min, const float* t_max,
                                       const float* density, int64_t n_rays, int32_t t,
                                       float* probs, lnrf_stream_t stream) {
+  if (n_rays == 0) return LNRF_OK;
   LNRF_CHECK_ARG(ts && t_min && t_max && density && probs, "null pointer");
   LNRF_CHECK_ARG(n_rays >= 0 && t >= 1, "bad sizes");
   if (n_rays == 0) return LNRF_OK;
@@ -557,6 +561,7 @@ extern "C" int lnrf_composite_fwd(const float* rays, int64_t ray_stride, const f
                                   float* outputs, float* alphas, float* coords, float* aux_sum,
                                   const float* targets, int64_t target_stride, float* sq_err,
                                   lnrf_stream_t stream) {
+  if (n_rays == 0) return LNRF_OK;
   LNRF_CHECK_ARG(ts && t_min && t_max && mask && density && rgb && background, "null pointer");
   LNRF_CHECK_ARG(n_rays >= 0 && t >= 1, "bad sizes");
   LNRF_CHECK_ARG(n_aux >= 0 && n_aux <= kMaxAux && (n_aux == 0 || aux), "bad aux");
@@ -579,6 +584,7 @@ extern "C" int lnrf_composite_bwd(const float* ts, const float* t_min, const flo
                                   int64_t target_stride, float out_scale, const float* g_aux_w,
                                   float* g_density, float* g_rgb, float* g_aux,
                                   float* g_background, lnrf_stream_t stream) {
+  if (n_rays == 0) return LNRF_OK;
   LNRF_CHECK_ARG(ts && t_min && t_max && mask && density && rgb && background, "null pointer");
   LNRF_CHECK_ARG(g_density && g_rgb, "null gradient outputs");
   LNRF_CHECK_ARG(g_out || (outputs && targets), "need g_out or outputs+targets");
@@ -601,6 +607,7 @@ extern "C" int lnrf_fine_sample(const float* ts_c, const float* t_min, const flo
                                 float eps, int32_t combine, const float* u, uint64_t seed,
                                 uint32_t stream_id, int64_t ray_offset, float* ts_out,
                                 lnrf_stream_t stream) {
+  if (n_rays == 0) return LNRF_OK;
   LNRF_CHECK_ARG(ts_c && t_min && t_max && density_c && ts_out, "null pointer");
   LNRF_CHECK_ARG(n_rays >= 0 && tc >= 1 && tf >= 0, "bad sizes");
   if (n_rays == 0) return LNRF_OK;
@@ -617,6 +624,7 @@ extern "C" int lnrf_fine_sample(const float* ts_c, const float* t_min, const flo
 
 extern "C" int lnrf_bin_edges(const float* ts, const float* t_min, const float* t_max, int64_t n_rays,
                               int32_t t, float* starts, float* ends, lnrf_stream_t stream) {
+  if (n_rays == 0 || t == 0) return LNRF_OK;
   LNRF_CHECK_ARG(ts && t_min && t_max, "null pointer");
   LNRF_CHECK_ARG(n_rays >= 0 && t >= 0, "bad sizes");
   if (n_rays == 0 || t == 0) return LNRF_OK;
