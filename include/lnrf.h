@@ -295,6 +295,37 @@ int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, co
 
 /* ------------------------------------------------------------- optimiser ---- */
 
+/* ---- fused InstantNGPModel MLP (reference learn_nerf/instant_ngp.py:38-54: the Dense stack after the
+ * MultiresHashTableEncoding: Dense(hidden) relu x density_layers, Dense(density_dim), density = exp(out[:, :1]),
+ * concat [sinusoidal_emb(d), out], Dense(hidden) relu x color_layers, tanh(Dense(3))).  bf16 MFMA operands,
+ * fp32 accumulate.  Fused configuration: hidden_dim 64, density_dim 16, density_layers 1, color_layers 2,
+ * d_freqs 4 (the reference defaults) and enc_dim = L*F <= 32; anything else returns LNRF_ERR_UNSUPPORTED and the
+ * caller uses lnrf_dense_* / lnrf_gemm_f32.  dense_offset = float offset of Dense_0/kernel in the flat parameter
+ * vector (parameters are laid out Dense_i kernel [fan_in][fan_out] then bias, i = 0..4). */
+typedef struct lnrf_ngp_mlp_desc {
+  int32_t enc_dim;        /* L * table_feature_dim */
+  int32_t hidden_dim;
+  int32_t density_dim;
+  int32_t density_layers;
+  int32_t color_layers;
+  int32_t d_freqs;
+  int64_t dense_offset;
+} lnrf_ngp_mlp_desc;
+
+int64_t lnrf_ngp_mlp_packed_bytes(const lnrf_ngp_mlp_desc* desc);
+int64_t lnrf_ngp_mlp_scratch_bytes(const lnrf_ngp_mlp_desc* desc, int64_t m);
+/* params: the flat fp32 parameter vector (tables included); packed: lnrf_ngp_mlp_packed_bytes bytes. */
+int lnrf_ngp_mlp_pack(const lnrf_ngp_mlp_desc* desc, const float* params, void* packed, lnrf_stream_t stream);
+/* enc_t: [enc_dim][m] feature-major output of lnrf_hashgrid_fwd; d: [m][3]; density [m], rgb [m][3]. */
+int lnrf_ngp_mlp_fwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t, const float* d,
+                     int64_t m, float* density, float* rgb, lnrf_stream_t stream);
+/* VJP of lnrf_ngp_mlp_fwd (recomputes the forward): g_enc_t [enc_dim][m] = d loss / d enc (written),
+ * grads (the flat gradient vector, same layout as params) += Dense kernel / bias gradients.
+ * scratch: lnrf_ngp_mlp_scratch_bytes(desc, m) bytes. */
+int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t, const float* d,
+                     const float* g_density, const float* g_rgb, int64_t m, void* scratch, float* g_enc_t,
+                     float* grads, lnrf_stream_t stream);
+
 /* optax.adam (train.py:59), fused over a flat buffer:
  *   g' = g*grad_scale; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
  *   p -= lr * (m/(1-b1^step)) / (sqrt(v/(1-b2^step)) + eps).   step counts from 1. */

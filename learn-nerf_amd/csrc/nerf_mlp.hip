@@ -9,45 +9,11 @@
 //            gradients dy_l and dumps them, (2) a split-K MFMA kernel reduces
 //            dW_l = X_l^T dy_l over all evaluations from the forward/backward dumps.
 // Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / positional encoding.
-#include <utility>
-
-#include "common.h"
-#include "fast_math.h"
-#include "nerf_layout.h"
+#include "fused_chain.h"
 
 namespace lnrf {
-using namespace nl;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-constexpr int kWaves = 8;            // waves per workgroup
-constexpr int kThreads = kWaves * 64;
-constexpr int kTileCols = 32;        // evaluations per wave
-constexpr int kStageBytes = kStageFrags * kFragBytes;  // 16 KiB
-constexpr int kSlots = 3;            // LDS stages: being read, published-next, being written
-constexpr int kRingBytes = kSlots * kStageBytes;
-constexpr int kBiasLdsOff = kRingBytes;
 constexpr int kFusedLds = kRingBytes + round_up(kBiasFloats * 4, 1024);
-constexpr int kFragAhead = 4;        // A-fragments read from LDS ahead of the MFMA that uses them
-
-extern __shared__ __attribute__((aligned(16))) char smem[];
-
-__device__ __forceinline__ bf16x8 bits_to_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ uint4 frag_to_bits(bf16x8 v) { return __builtin_bit_cast(uint4, v); }
-__device__ __forceinline__ bf16x8 zero_frag() { return bits_to_frag(make_uint4(0, 0, 0, 0)); }
 
 struct FwdSeq {
   static constexpr int count = kFwdUsed;
@@ -57,170 +23,6 @@ struct BwdSeq {
   static constexpr int count = kBwdUsed;
   static constexpr int at(int c) { return bwd_seq(c); }
 };
-
-// The weight ring.  A stage is 16 fragments (16 KiB) shared by the 8 waves; every wave moves 2 of
-// them.  Staging is global -> VGPR -> LDS (not LDS-DMA: hipcc drains vmcnt(0) before any ds_read
-// while an LDS-DMA is pending, which serialises the pipeline).  Timeline at the barrier that opens
-// stage T: stage T+1 is already in LDS and becomes visible (it was written after barrier T-1), stage
-// T+2 is written from registers into the slot freed by stage T-1, stage T+4 is requested from L2.
-// Because stage T+1 is visible during stage T, the per-wave FIFO of A-fragments (kFragAhead LDS reads
-// in flight) runs continuously across stage boundaries.
-template <int NSTAGES, class SEQ>
-struct Ring {
-  const char* stream;  // global, NSTAGES * 16 KiB, fragment order
-  int wave, lane;
-  uint4 r[2][2];
-  bf16x8 fifo[kFragAhead];
-
-  template <int T>
-  __device__ __forceinline__ void load() {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = wave + kWaves * q;
-      r[T & 1][q] = *reinterpret_cast<const uint4*>(stream + ((int64_t)T * kStageFrags + f) * kFragBytes +
-                                                    lane * 16);
-    }
-  }
-  template <int T>
-  __device__ __forceinline__ void write() {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = wave + kWaves * q;
-      *reinterpret_cast<uint4*>(&smem[(T % kSlots) * kStageBytes + f * kFragBytes + lane * 16]) = r[T & 1][q];
-    }
-  }
-  template <int G>
-  __device__ __forceinline__ bf16x8 read_lds() const {
-    constexpr int off = ((G / kStageFrags) % kSlots) * kStageBytes + (G % kStageFrags) * kFragBytes;
-    return bits_to_frag(*reinterpret_cast<const uint4*>(&smem[off + lane * 16]));
-  }
-  // loads stages 0..3, publishes stages 0 and 1, fills the fragment FIFO
-  __device__ __forceinline__ void prologue() {
-    load<0>();
-    if constexpr (NSTAGES > 1) load<1>();
-    write<0>();
-    if constexpr (NSTAGES > 1) write<1>();
-    if constexpr (NSTAGES > 2) load<2>();
-    if constexpr (NSTAGES > 3) load<3>();
-    __syncthreads();
-    if constexpr (NSTAGES > 2) write<2>();  // the work of the (implicit) barrier that opens stage 0
-    if constexpr (NSTAGES > 4) load<4>();
-    static_for<kFragAhead>([&](auto i) {
-      constexpr int c = decltype(i)::value;
-      if constexpr (c < SEQ::count) fifo[c] = read_lds<SEQ::at(c)>();
-    });
-  }
-  // barrier that opens stage T (T >= 1): frees the slot of stage T-1, publishes stage T+1
-  template <int T>
-  __device__ __forceinline__ void advance() {
-    __syncthreads();
-    if constexpr (T + 2 < NSTAGES) write<T + 2>();
-    if constexpr (T + 4 < NSTAGES) load<T + 4>();
-  }
-  // fragment of consumption index C (and request the one kFragAhead later)
-  template <int C>
-  __device__ __forceinline__ bf16x8 next() {
-    constexpr int g = SEQ::at(C);
-    if constexpr (g % kStageFrags == 0 && g > 0) advance<g / kStageFrags>();
-    const bf16x8 a = fifo[C % kFragAhead];
-    if constexpr (C + kFragAhead < SEQ::count) fifo[C % kFragAhead] = read_lds<SEQ::at(C + kFragAhead)>();
-    return a;
-  }
-};
-
-// accumulator initialised with the fp32 bias of rows 32*o.. (LDS block, broadcast reads)
-__device__ __forceinline__ f32x16 bias_acc(int bias_row0, int h) {
-  f32x16 acc;
-  const float* b = reinterpret_cast<const float*>(&smem[kBiasLdsOff]) + bias_row0 + 4 * h;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(b + 8 * g);
-    acc[4 * g + 0] = v.x;
-    acc[4 * g + 1] = v.y;
-    acc[4 * g + 2] = v.z;
-    acc[4 * g + 3] = v.w;
-  }
-  return acc;
-}
-__device__ __forceinline__ f32x16 zero_acc() {
-  f32x16 acc;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  return acc;
-}
-
-// registers 8s..8s+7 of an accumulator tile -> B-frag of k-step s of the next layer
-template <int S, bool RELU>
-__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& acc) {
-  bf16x8 f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = acc[8 * S + j];
-    if (RELU) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());  // max(v, 0) in one VALU op
-    f[j] = (__bf16)v;
-  }
-  return f;
-}
-
-// ReLU mask of one out-tile from its two bf16 output fragments: bit 8s + j set <=> element j of
-// fragment s is non-zero (ReLU output > 0), i.e. accumulator register 8s + j passed the ReLU
-__device__ __forceinline__ unsigned relu_bits(const bf16x8& f0, const bf16x8& f1) {
-  const uint4 a = frag_to_bits(f0), b = frag_to_bits(f1);
-  const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  unsigned bits = 0u;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    bits |= ((w[i] & 0xFFFFu) != 0u ? 1u : 0u) << (2 * i);
-    bits |= ((w[i] >> 16) != 0u ? 1u : 0u) << (2 * i + 1);
-  }
-  return bits;
-}
-// dy = dh * mask: registers 8s..8s+7 of the tile whose 16 mask bits start at bit `shift` of `bits`
-template <int S>
-__device__ __forceinline__ bf16x8 masked_frag(const f32x16& acc, unsigned bits, int shift) {
-  bf16x8 f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = (__bf16)(((bits >> (shift + 8 * S + j)) & 1u) ? acc[8 * S + j] : 0.0f);
-  return f;
-}
-
-// the activation / gradient dumps are written once and read by a later kernel: non-temporal stores keep
-// them from displacing the L2-resident weight stream
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void stream_store(char* p, uint4 v) {
-  u32x4 t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
-}
-
-struct DumpAddr {
-  char* base;       // [slot][tile][1 KiB]
-  int64_t n_tiles;  // tiles in the buffer
-  int64_t tile;
-  int c, hh;
-  __device__ __forceinline__ char* at(int slot) const {
-    return base + ((int64_t)slot * n_tiles + tile) * kFragBytes + dump_lane_off(slot, c, hh);
-  }
-};
-
-// One GEMM layer of the fused chain: for each 32-row out tile, for each k-step, one MFMA.
-// C0 = consumption index of the layer's first fragment.
-template <int C0, int NK, int NO, class RING, class Init, class GetB, class Epi>
-__device__ __forceinline__ void chain_layer(RING& ring, Init init, GetB getb, Epi epi) {
-  static_for<NO>([&](auto o_) {
-    constexpr int o = decltype(o_)::value;
-    f32x16 acc = init(o_);
-    static_for<NK>([&](auto k_) {
-      constexpr int ks = decltype(k_)::value;
-      const bf16x8 a = ring.template next<C0 + o * NK + ks>();
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, getb(k_), acc, 0, 0, 0);
-      // Keep the software pipeline the source expresses (one LDS fragment read, for the MFMA kFragAhead
-      // steps later, per MFMA) instead of the scheduler's read-wait-use pairs.  A plain scheduling fence
-      // per step does it; sched_group_barrier gives the same code but costs ~15 min of compile time here.
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    epi(o_, acc);
-  });
-}
 
 // ---------------------------------------------------------------------------------------------
 // Forward
@@ -546,220 +348,32 @@ struct WgradArgs {
   int n_problems;
 };
 
-// operand tile = 32 features (fragment pair starting at frag_even) x 16 evaluations (half q of the
-// step).  Lane l receives feature l&31 and evaluations 16q + 8(l>>5) + j, j = 0..7.
-__device__ __forceinline__ bf16x8 tr_frag(const char* frag_even, int lane, int parity, int q) {
-  const int g = lane >> 4;             // 16-lane group
-  const int i = lane & 15;             // supplies block row qp = i>>2 (evaluation), piece p = i&3
-  const int frag = g & 1;              // which fragment of the pair (features 0-15 / 16-31)
-  const int hk = g >> 1;               // k half
-  const int qp = i >> 2, p = i & 3;
-  const int slot_par = parity ^ frag;  // slot parity of that fragment (see dump_lane_off)
-  const int c0 = 16 * q + 8 * hk;
-  const int ca = c0 + qp, cb = c0 + 4 + qp;
-  const char* base = frag_even + frag * kFragBytes;
-  const int offa = 256 * (ca >> 3) + 128 * (((ca >> 2) & 1) ^ slot_par) + 64 * (p & 1) + 16 * (ca & 3) + 8 * (p >> 1);
-  const int offb = 256 * (cb >> 3) + 128 * (((cb >> 2) & 1) ^ slot_par) + 64 * (p & 1) + 16 * (cb & 3) + 8 * (p >> 1);
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + offa));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + offb));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v;
-  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-// global -> VGPR -> LDS staging of one iteration = SPI consecutive 32-evaluation steps
-// (NXF + NYF fragments each, 8 waves).  The registers hold the iteration that is written to LDS
-// after the next barrier; its loads were issued one whole iteration earlier.
-template <int NXF, int NYF, int SPI>  // SPI = steps per iteration (per barrier)
-struct WgStage {
-  static constexpr int kWgSpi = SPI;
-  static constexpr int NF = NXF + NYF;
-  static constexpr int PER_WAVE = (NF + kWaves - 1) / kWaves;
-  static constexpr int STEP_BYTES = NF * kFragBytes;
-  static constexpr int ITER_BYTES = kWgSpi * STEP_BYTES;
-  const char* x_src;  // slot x_slot0, first tile of this K-slice, + lane*16
-  const char* y_src;
-  int64_t slot_stride;  // bytes between consecutive slots (= n_tiles KiB)
-  int64_t steps;        // steps in this K-slice
-  int wave, lane;
-  uint4 rr[kWgSpi][PER_WAVE];
-
-  // fragment q of this wave is f = wave + 8q; when NF is not a multiple of 8 the surplus waves of
-  // the last round re-load fragment NF-1 (harmless duplicate, keeps the loop branch-free).
-  // Steps past the end of the K-slice are staged as zeros (they contribute nothing).
-  __device__ __forceinline__ void load(int64_t iter) {
-#pragma unroll
-    for (int u = 0; u < kWgSpi; ++u) {
-      const int64_t step = iter * kWgSpi + u;
-      const bool ok = step < steps;
-      const int64_t st = ok ? step : 0;
-      const unsigned keep = ok ? 0xFFFFFFFFu : 0u;  // branch-free zeroing of out-of-range steps
-#pragma unroll
-      for (int q = 0; q < PER_WAVE; ++q) {
-        int f = wave + kWaves * q;
-        if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
-        const char* src = f < NXF ? x_src + (int64_t)f * slot_stride : y_src + (int64_t)(f - NXF) * slot_stride;
-        // read-once operands: non-temporal loads leave L2 / Infinity Cache to data that is reused
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + st * kFragBytes));
-        rr[u][q] = make_uint4(v[0] & keep, v[1] & keep, v[2] & keep, v[3] & keep);
-      }
+// NeRFModel gradient-vector addressing for the shared weight-gradient body
+struct NerfWgradEpi {
+  static __device__ __forceinline__ void cols(const WgradProblem& pb, int ot, int colr, int& out_idx, int& out_dim,
+                                              int64_t& w_off, int64_t& b_off) {
+    int dense_w = pb.dense;
+    if (pb.col_map == COL_DY10M) {  // tiles 0..3 = Dense_10 outputs, tile 4 column 0 = Dense_9
+      if (ot < 4) { out_idx = 32 * ot + colr; out_dim = 128; dense_w = 10; }
+      else if (colr == 0 && pb.row_map == ROW_HIDDEN) { out_idx = 0; out_dim = 1; dense_w = 9; }
+    } else if (pb.col_map == COL_DY11) {
+      if (colr < 3) { out_idx = colr; out_dim = 3; }
+    } else {
+      out_idx = 32 * ot + colr; out_dim = 256;
     }
+    w_off = dense_w_off(dense_w);
+    b_off = dense_b_off(dense_w);
   }
-  template <int B>
-  __device__ __forceinline__ void write() {
-#pragma unroll
-    for (int u = 0; u < kWgSpi; ++u) {
-#pragma unroll
-      for (int q = 0; q < PER_WAVE; ++q) {
-        int f = wave + kWaves * q;
-        if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
-        *reinterpret_cast<uint4*>(&smem[B * ITER_BYTES + u * STEP_BYTES + f * kFragBytes + lane * 16]) = rr[u][q];
-      }
-    }
+  static __device__ __forceinline__ int row(const WgradProblem& pb, int f, int r16) {
+    const int sh = (r16 >> 2) & 1, sj = 4 * (r16 >> 3) + (r16 & 3);  // slot (h, j) of that feature
+    int in_idx;
+    if (pb.row_map == ROW_HIDDEN) in_idx = 16 * f + r16;
+    else if (pb.row_map == ROW_XEMB) in_idx = xemb_feat(f, sh, sj);
+    else in_idx = demb_feat(f, sh, sj);
+    return in_idx >= 0 ? in_idx + pb.row_off : -1;
   }
 };
 
-template <int NXF, int NYF, int WI, int WO, int SPI>
-__device__ __forceinline__ void wgrad_body(const WgradProblem& pb, const char* __restrict__ save,
-                                           const char* __restrict__ gdump, int64_t n_tiles,
-                                           float* __restrict__ grads) {
-  constexpr int NI = NXF / 2, NO = NYF / 2;
-  constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;  // tiles per wave
-  constexpr bool FULL_I = TI * WI == NI, FULL_O = TO * WO == NO;   // every wave owns TI x TO real tiles
-  using Stage = WgStage<NXF, NYF, SPI>;
-  constexpr int kWgSpi = SPI;
-  static_assert(WI * WO == kWaves, "wave grid");
-  static_assert(NXF % 2 == 0 && NYF % 2 == 0, "fragment pairs");
-
-  const int split = blockIdx.x - pb.first_block;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave / WO, wo = wave % WO;
-
-  const int64_t per = (n_tiles + pb.n_blocks - 1) / pb.n_blocks;
-  const int64_t t0 = (int64_t)split * per;
-  const int64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
-  const int64_t steps = t1 > t0 ? t1 - t0 : 0;
-  const int64_t iters = (steps + kWgSpi - 1) / kWgSpi;
-
-  Stage stg;
-  stg.x_src = save + ((int64_t)pb.x_slot0 * n_tiles + t0) * kFragBytes + lane * 16;
-  stg.y_src = gdump + ((int64_t)pb.y_slot0 * n_tiles + t0) * kFragBytes + lane * 16;
-  stg.slot_stride = n_tiles * kFragBytes;
-  stg.steps = steps;
-  stg.wave = wave;
-  stg.lane = lane;
-
-  f32x16 acc[TI][TO];
-#pragma unroll
-  for (int a = 0; a < TI; ++a)
-#pragma unroll
-    for (int b = 0; b < TO; ++b) acc[a][b] = zero_acc();
-  float bsum[TO];
-#pragma unroll
-  for (int b = 0; b < TO; ++b) bsum[b] = 0.0f;
-  const int ypar = pb.y_slot0 & 1, xpar = pb.x_slot0 & 1;  // slot parity of even fragments
-
-  auto compute = [&](auto buf_) {
-    constexpr int bufi = decltype(buf_)::value;
-#pragma unroll
-    for (int u = 0; u < kWgSpi; ++u) {
-      const char* buf = smem + bufi * Stage::ITER_BYTES + u * Stage::STEP_BYTES;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bf16x8 bf[TO];
-#pragma unroll
-        for (int b = 0; b < TO; ++b) {
-          const int ot = wo + WO * b;
-          if (FULL_O || ot < NO) {
-            bf[b] = tr_frag(buf + (NXF + 2 * ot) * kFragBytes, lane, ypar, q);
-            if (wi == 0) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) bsum[b] += (float)bf[b][j];
-            }
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < TI; ++a) {
-          const int it = wi + WI * a;
-          if (FULL_I || it < NI) {
-            const bf16x8 af = tr_frag(buf + 2 * it * kFragBytes, lane, xpar, q);
-#pragma unroll
-            for (int b = 0; b < TO; ++b) {
-              const int ot = wo + WO * b;
-              if (FULL_O || ot < NO)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[b], acc[a][b], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-  };
-  std::integral_constant<int, 0> c0;
-  std::integral_constant<int, 1> c1;
-  // iteration i: barrier | write iteration i+1 (registers) to LDS buffer (i+1)&1 | load iteration i+2 |
-  // compute iteration i from buffer i&1.  Loads stay in flight for one whole iteration of MFMA work.
-  if (iters > 0) {
-    stg.load(0);
-    stg.template write<0>();
-    stg.load(1);
-  }
-  for (int64_t i = 0; i < iters; i += 2) {
-    __syncthreads();
-    stg.template write<1>();
-    stg.load(i + 2);
-    compute(c0);
-    __syncthreads();
-    stg.template write<0>();
-    stg.load(i + 3);
-    if (i + 1 < iters) compute(c1);
-  }
-
-  // epilogue: atomically add the partial dW tiles / bias sums
-  const int colr = lane & 31, hh = lane >> 5;
-  static_for<TO>([&](auto b_) {
-    constexpr int b = decltype(b_)::value;
-    const int ot = wo + WO * b;
-    int out_idx = -1, out_dim = 1, dense_w = pb.dense;
-    if (ot < NO) {
-      if (pb.col_map == COL_DY10M) {  // tiles 0..3 = Dense_10 outputs, tile 4 column 0 = Dense_9
-        if (ot < 4) { out_idx = 32 * ot + colr; out_dim = 128; dense_w = 10; }
-        else if (colr == 0 && pb.row_map == ROW_HIDDEN) { out_idx = 0; out_dim = 1; dense_w = 9; }
-      } else if (pb.col_map == COL_DY11) {
-        if (colr < 3) { out_idx = colr; out_dim = 3; }
-      } else {
-        out_idx = 32 * ot + colr; out_dim = 256;
-      }
-    }
-    if (wi == 0 && pb.do_bias) {
-      float sacc = bsum[b];
-      sacc += __shfl_xor(sacc, 32, 64);
-      if (hh == 0 && out_idx >= 0) atomicAdd(grads + dense_b_off(dense_w) + out_idx, sacc);
-    }
-    static_for<TI>([&](auto a_) {
-      constexpr int a = decltype(a_)::value;
-      const int it = wi + WI * a;
-      static_for<16>([&](auto q_) {
-        constexpr int qq = decltype(q_)::value;
-        const int r = (qq & 3) + 8 * (qq >> 2) + 4 * hh;  // row in the 32-feature tile
-        const int f = 2 * it + (r >> 4);                   // k-step slot within X
-        const int r16 = r & 15;
-        const int sh = (r16 >> 2) & 1, sj = 4 * (r16 >> 3) + (r16 & 3);  // slot (h, j) of that feature
-        int in_idx;
-        if (pb.row_map == ROW_HIDDEN) in_idx = 16 * f + r16;
-        else if (pb.row_map == ROW_XEMB) in_idx = xemb_feat(f, sh, sj);
-        else in_idx = demb_feat(f, sh, sj);
-        if (it < NI && out_idx >= 0 && in_idx >= 0)
-          atomicAdd(grads + dense_w_off(dense_w) + (int64_t)(in_idx + pb.row_off) * out_dim + out_idx,
-                    acc[a][b][qq]);
-      });
-    });
-  });
-}
 
 // One launch for every Dense layer of the model: blockIdx -> problem -> operand-shape body.
 // Problems are listed heaviest first so that the small ones fill the tail of the launch.
@@ -772,11 +386,11 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
     if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
   switch (pb.shape) {
     // steps per barrier chosen so that every body keeps ~60 KB of loads in flight per workgroup
-    case 0: wgrad_body<16, 16, 4, 2, 2>(pb, save, gdump, n_tiles, grads); break;
-    case 1: wgrad_body<16, 10, 4, 2, 2>(pb, save, gdump, n_tiles, grads); break;
-    case 2: wgrad_body<4, 16, 2, 4, 3>(pb, save, gdump, n_tiles, grads); break;
-    case 3: wgrad_body<2, 10, 1, 8, 5>(pb, save, gdump, n_tiles, grads); break;
-    default: wgrad_body<8, 2, 4, 2, 6>(pb, save, gdump, n_tiles, grads); break;
+    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
+    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
+    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
+    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
+    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
   }
 }
 

@@ -1,0 +1,527 @@
+// ngp_mlp.hip — fused InstantNGPModel MLP (learn_nerf/instant_ngp.py:38-54) on the bf16 MFMA of gfx950.
+//
+//   enc (L*F hash-grid features) -> Dense_0 64 relu -> Dense_1 16 (density = exp(out[0]))
+//   [d_emb(24), out(16)] -> Dense_2 64 relu -> Dense_3 64 relu -> Dense_4 3 tanh
+//
+// Same construction as nerf_mlp.hip: one wave owns 32 evaluations, the f32 accumulator tile of a layer is
+// converted in place into the B operand of the next one, the packed A-fragment stream (26 + 20 fragments)
+// goes through the shared LDS ring.  The network is so small that the backward kernel recomputes the
+// forward (26 MFMAs) instead of reading saved activations, then runs the transposed chain, writes
+// d loss / d enc feature-major for the hash-grid scatter, and dumps X / dy fragments (about 1 KiB per
+// evaluation) for the shared split-K weight-gradient body.
+// Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / directional encoding.
+#include "fused_chain.h"
+
+namespace lnrf {
+
+constexpr int kNgpLayers = 5;
+constexpr int kNgpHidden = 64, kNgpDensityDim = 16, kNgpDembDim = 24;
+constexpr int kNgpStreamFrags = 48;                               // 3 ring stages
+constexpr int kNgpBiasFloats = 256;
+constexpr int kNgpPackBiasOff = kNgpStreamFrags * kFragBytes;
+constexpr int kNgpPackBytes = kNgpPackBiasOff + kNgpBiasFloats * 4;
+constexpr int kNgpLds = kRingBytes + 1024;
+
+// forward layer l: k-steps, 32-row out tiles, first fragment (consumption order == stream order)
+constexpr int ngp_fwd_nk(int l, int ne) { return l == 0 ? ne : (l == 2 ? 3 : 4); }
+constexpr int ngp_fwd_no(int l) { return (l == 1 || l == 4) ? 1 : 2; }
+constexpr int ngp_fwd_base(int l, int ne) {
+  int b = 0;
+  for (int i = 0; i < l; ++i) b += ngp_fwd_nk(i, ne) * ngp_fwd_no(i);
+  return b;
+}
+constexpr int ngp_fwd_count(int ne) { return ngp_fwd_base(kNgpLayers, ne); }
+// backward step t applies Dense_{4-t}^T
+constexpr int ngp_bwd_nk(int t) { return (t == 0 || t == 3) ? 1 : 4; }
+constexpr int ngp_bwd_no(int t) { return (t == 2 || t == 4) ? 1 : 2; }
+constexpr int ngp_bwd_base(int t, int ne) {
+  int b = ngp_fwd_count(ne);
+  for (int i = 0; i < t; ++i) b += ngp_bwd_nk(i) * ngp_bwd_no(i);
+  return b;
+}
+constexpr int ngp_total_count(int ne) { return ngp_bwd_base(kNgpLayers, ne); }
+constexpr int ngp_bias_base(int l) { return l == 0 ? 0 : (l == 1 ? 64 : (l == 2 ? 96 : (l == 3 ? 160 : 224))); }
+__host__ __device__ constexpr int ngp_out_dim(int l) { return l == 1 ? kNgpDensityDim : (l == 4 ? 3 : kNgpHidden); }
+
+// dump slots of the backward scratch ([slot][tile][1 KiB]): X tensors then dy tensors
+constexpr int kNgpXEnc = 0, kNgpXH0 = 2, kNgpXCat = 6, kNgpXC1 = 10, kNgpXC2 = 14;
+constexpr int kNgpDy0 = 18, kNgpDy1 = 22, kNgpDy2 = 24, kNgpDy3 = 28, kNgpDy4 = 32;
+constexpr int kNgpSlots = 34;
+
+template <int NE, bool BWD>
+struct NgpSeq {
+  static constexpr int count = BWD ? ngp_total_count(NE) : ngp_fwd_count(NE);
+  static constexpr int at(int c) { return c; }
+};
+
+// dh * relu'(h): keep accumulator registers 8S..8S+7 where the bf16 activation fragment is non-zero
+template <int S>
+__device__ __forceinline__ bf16x8 masked_by(const f32x16& acc, const bf16x8& ref) {
+  const uint4 rb = frag_to_bits(ref);
+  const unsigned w[4] = {rb.x, rb.y, rb.z, rb.w};
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned e = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu);
+    f[j] = (__bf16)(e != 0u ? acc[8 * S + j] : 0.0f);
+  }
+  return f;
+}
+
+template <int NE, bool BWD>
+__global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
+    const char* __restrict__ packed, const float* __restrict__ enc_t, const float* __restrict__ d_g, int lf,
+    int64_t M, int64_t n_tiles, float* __restrict__ density, float* __restrict__ rgb,
+    const float* __restrict__ g_density, const float* __restrict__ g_rgb, char* __restrict__ scratch,
+    float* __restrict__ g_enc_t) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  const bool tile_ok = tile < n_tiles;
+
+  {
+    const float* bias_g = reinterpret_cast<const float*>(packed + kNgpPackBiasOff);
+    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
+    for (int i = tid; i < kNgpBiasFloats; i += kThreads) bias_l[i] = bias_g[i];
+  }
+  // encoding fragments: k slot (ks, h, j) <-> feature 16 ks + 8 (j >> 2) + 4 h + (j & 3) (row of enc_t)
+  bf16x8 ef[NE];
+  static_for<NE>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int feat = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+      const float v = (valid && feat < lf) ? enc_t[(int64_t)feat * M + m] : 0.0f;
+      ef[ks][j] = (__bf16)v;
+    }
+  });
+  float pd[3] = {0, 0, 0};
+  float gy4[3] = {0, 0, 0}, g_dens = 0.0f;
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pd[a] = d_g[m * 3 + a];
+    if (BWD && h == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gy4[k] = g_rgb[m * 3 + k];
+      g_dens = g_density[m];
+    }
+  }
+  __syncthreads();
+
+  using Seq = NgpSeq<NE, BWD>;
+  Ring<(Seq::count + kStageFrags - 1) / kStageFrags, Seq> ring;
+  ring.stream = packed;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+
+  // sinusoidal direction embedding (model.py:65-77): feature e = 8 coord + 4 is_cos + freq, slot order = e
+  bf16x8 de[2];
+  static_for<2>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+      float v = 0.0f;
+      if (e < kNgpDembDim) {
+        const int cd = e >> 3, fr = e & 3;
+        const float x = cd == 0 ? pd[0] : (cd == 1 ? pd[1] : pd[2]);
+        float s, co;
+        sincos_pe(x * (float)(1 << fr), &s, &co);
+        v = (e & 4) ? co : s;
+      }
+      de[ks][j] = (__bf16)v;
+    }
+  });
+
+  DumpAddr dump{scratch, n_tiles, tile, c, h};
+  auto dump_frag = [&](int slot, const bf16x8& f) {
+    if (BWD && tile_ok) stream_store(dump.at(slot), frag_to_bits(f));
+  };
+
+  bf16x8 h0[4], o16, c1[4], c2[4];
+  float logit = 0.0f;
+  // Dense_0 + relu
+  chain_layer<ngp_fwd_base(0, NE), NE, 2>(
+      ring, [&](auto o_) { return bias_acc(ngp_bias_base(0) + 32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 { return ef[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        h0[2 * o] = acc_to_frag<0, true>(acc);
+        h0[2 * o + 1] = acc_to_frag<1, true>(acc);
+      });
+  // Dense_1 (linear): 16 features = rows 0..15 of the tile; density logit = feature 0
+  chain_layer<ngp_fwd_base(1, NE), 4, 1>(
+      ring, [&](auto) { return bias_acc(ngp_bias_base(1), h); },
+      [&](auto k_) -> bf16x8 { return h0[decltype(k_)::value]; },
+      [&](auto, const f32x16& acc) {
+        o16 = acc_to_frag<0, false>(acc);
+        logit = acc[0];
+      });
+  const float dens = __expf(logit);  // instant_ngp.py:49, valid on lanes h == 0
+  // Dense_2 + relu on [d_emb, out]
+  chain_layer<ngp_fwd_base(2, NE), 3, 2>(
+      ring, [&](auto o_) { return bias_acc(ngp_bias_base(2) + 32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 {
+        constexpr int ks = decltype(k_)::value;
+        if constexpr (ks < 2) return de[ks];
+        else return o16;
+      },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        c1[2 * o] = acc_to_frag<0, true>(acc);
+        c1[2 * o + 1] = acc_to_frag<1, true>(acc);
+      });
+  // Dense_3 + relu
+  chain_layer<ngp_fwd_base(3, NE), 4, 2>(
+      ring, [&](auto o_) { return bias_acc(ngp_bias_base(3) + 32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 { return c1[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        c2[2 * o] = acc_to_frag<0, true>(acc);
+        c2[2 * o + 1] = acc_to_frag<1, true>(acc);
+      });
+  // Dense_4 + tanh
+  float y[3] = {0, 0, 0};
+  chain_layer<ngp_fwd_base(4, NE), 4, 1>(
+      ring, [&](auto) { return bias_acc(ngp_bias_base(4), h); },
+      [&](auto k_) -> bf16x8 { return c2[decltype(k_)::value]; },
+      [&](auto, const f32x16& acc) {
+        y[0] = tanhf(acc[0]);
+        y[1] = tanhf(acc[1]);
+        y[2] = tanhf(acc[2]);
+      });
+  if constexpr (!BWD) {
+    if (h == 0 && valid) {
+      density[m] = dens;
+      rgb[m * 3 + 0] = y[0];
+      rgb[m * 3 + 1] = y[1];
+      rgb[m * 3 + 2] = y[2];
+    }
+    return;
+  } else {
+    // ---- backward: X dumps for the weight gradients
+    static_for<2>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      if constexpr (i < NE) dump_frag(kNgpXEnc + i, ef[i]);
+      else dump_frag(kNgpXEnc + i, zero_frag());
+    });
+    static_for<4>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      dump_frag(kNgpXH0 + i, h0[i]);
+      dump_frag(kNgpXC1 + i, c1[i]);
+      dump_frag(kNgpXC2 + i, c2[i]);
+    });
+    dump_frag(kNgpXCat + 0, de[0]);
+    dump_frag(kNgpXCat + 1, de[1]);
+    dump_frag(kNgpXCat + 2, o16);
+    dump_frag(kNgpXCat + 3, zero_frag());
+
+    // head gradients in fp32: tanh' and exp'
+    bf16x8 dy4 = zero_frag();
+    dy4[0] = (__bf16)(gy4[0] * (1.0f - y[0] * y[0]));
+    dy4[1] = (__bf16)(gy4[1] * (1.0f - y[1] * y[1]));
+    dy4[2] = (__bf16)(gy4[2] * (1.0f - y[2] * y[2]));
+    if (h != 0) dy4 = zero_frag();
+    const float g_logit = h == 0 ? g_dens * dens : 0.0f;
+    dump_frag(kNgpDy4, dy4);
+    dump_frag(kNgpDy4 + 1, zero_frag());
+
+    bf16x8 dy3[4], dy2[4], dy1, dy0[4];
+    // T0: Dense_4^T -> dc2, relu mask of c2
+    chain_layer<ngp_bwd_base(0, NE), 1, 2>(
+        ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy4; },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          dy3[2 * o] = masked_by<0>(acc, c2[2 * o]);
+          dy3[2 * o + 1] = masked_by<1>(acc, c2[2 * o + 1]);
+          dump_frag(kNgpDy3 + 2 * o, dy3[2 * o]);
+          dump_frag(kNgpDy3 + 2 * o + 1, dy3[2 * o + 1]);
+        });
+    // T1: Dense_3^T -> dc1, relu mask of c1
+    chain_layer<ngp_bwd_base(1, NE), 4, 2>(
+        ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy3[decltype(k_)::value]; },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          dy2[2 * o] = masked_by<0>(acc, c1[2 * o]);
+          dy2[2 * o + 1] = masked_by<1>(acc, c1[2 * o + 1]);
+          dump_frag(kNgpDy2 + 2 * o, dy2[2 * o]);
+          dump_frag(kNgpDy2 + 2 * o + 1, dy2[2 * o + 1]);
+        });
+    // T2: Dense_2^T restricted to the rows of `out` (d_emb has no parameters upstream); the density
+    // head adds d exp(out_0) to feature 0 (lane h == 0, register 0)
+    chain_layer<ngp_bwd_base(2, NE), 4, 1>(
+        ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy2[decltype(k_)::value]; },
+        [&](auto, const f32x16& acc) {
+          f32x16 t = acc;
+          t[0] += g_logit;
+          dy1 = acc_to_frag<0, false>(t);
+          dump_frag(kNgpDy1, dy1);
+          dump_frag(kNgpDy1 + 1, zero_frag());
+        });
+    // T3: Dense_1^T -> dh0, relu mask of h0
+    chain_layer<ngp_bwd_base(3, NE), 1, 2>(
+        ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy1; },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          dy0[2 * o] = masked_by<0>(acc, h0[2 * o]);
+          dy0[2 * o + 1] = masked_by<1>(acc, h0[2 * o + 1]);
+          dump_frag(kNgpDy0 + 2 * o, dy0[2 * o]);
+          dump_frag(kNgpDy0 + 2 * o + 1, dy0[2 * o + 1]);
+        });
+    // T4: Dense_0^T -> d loss / d enc, feature-major fp32 for the hash-grid scatter
+    chain_layer<ngp_bwd_base(4, NE), 4, 1>(
+        ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy0[decltype(k_)::value]; },
+        [&](auto, const f32x16& acc) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (valid && row < lf) g_enc_t[(int64_t)row * M + m] = acc[q];
+          }
+        });
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients: the shared split-K body with InstantNGP addressing
+// ---------------------------------------------------------------------------------------------
+struct NgpWgradProblem {
+  int shape, x_slot0, y_slot0, do_bias, first_block, n_blocks;
+  int out_dim;             // columns of the Flax kernel (= valid dy features)
+  unsigned w_lo, w_hi, b_lo, b_hi;  // float offsets of kernel / bias in the gradient vector (64-bit, split)
+  int rb0, rb1, rb2, rb3;  // per X fragment: first kernel row ...
+  int rv0, rv1, rv2, rv3;  // ... and how many of its 16 features are real (scalars: keeps the struct in SGPRs)
+};
+struct NgpWgradArgs {
+  NgpWgradProblem p[kNgpLayers];
+};
+struct NgpWgradEpi {
+  static __device__ __forceinline__ void cols(const NgpWgradProblem& pb, int ot, int colr, int& out_idx,
+                                              int& out_dim, int64_t& w_off, int64_t& b_off) {
+    const int idx = 32 * ot + colr;
+    out_idx = idx < pb.out_dim ? idx : -1;
+    out_dim = pb.out_dim;
+    w_off = (int64_t)(((uint64_t)pb.w_hi << 32) | pb.w_lo);
+    b_off = (int64_t)(((uint64_t)pb.b_hi << 32) | pb.b_lo);
+  }
+  static __device__ __forceinline__ int row(const NgpWgradProblem& pb, int f, int r16) {
+    const int base = f == 0 ? pb.rb0 : (f == 1 ? pb.rb1 : (f == 2 ? pb.rb2 : pb.rb3));
+    const int nv = f == 0 ? pb.rv0 : (f == 1 ? pb.rv1 : (f == 2 ? pb.rv2 : pb.rv3));
+    return r16 < nv ? base + r16 : -1;
+  }
+};
+constexpr int kNgpWgSpi = 6;  // steps per barrier
+constexpr int kNgpWgradLds = 2 * kNgpWgSpi * 8 * kFragBytes;
+
+__global__ __launch_bounds__(kThreads) void ngp_wgrad_kernel(NgpWgradArgs args, const char* __restrict__ scratch,
+                                                             int64_t n_tiles, float* __restrict__ grads) {
+  NgpWgradProblem pb = args.p[0];
+#pragma unroll
+  for (int i = 1; i < kNgpLayers; ++i)
+    if ((int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
+  switch (pb.shape) {
+    case 0: wgrad_body<2, 4, 1, 8, kNgpWgSpi, NgpWgradEpi>(pb, scratch, scratch, n_tiles, grads); break;
+    case 1: wgrad_body<4, 2, 2, 4, kNgpWgSpi, NgpWgradEpi>(pb, scratch, scratch, n_tiles, grads); break;
+    default: wgrad_body<4, 4, 2, 4, kNgpWgSpi, NgpWgradEpi>(pb, scratch, scratch, n_tiles, grads); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: flat fp32 parameters -> bf16 A-fragment stream (forward then transposed) + fp32 biases
+// ---------------------------------------------------------------------------------------------
+struct NgpOffsets {
+  int64_t w[kNgpLayers], b[kNgpLayers];
+};
+
+__global__ void ngp_pack_kernel(const float* __restrict__ params, NgpOffsets off, int lf, int ne,
+                                char* __restrict__ packed) {
+  const int total_frag_elems = kNgpStreamFrags * 512;
+  const int total = total_frag_elems + kNgpBiasFloats;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    if (e < total_frag_elems) {
+      const int g = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+      const int r = lane & 31, hh = lane >> 5;
+      const int fo = 8 * (j >> 2) + 4 * hh + (j & 3);  // feature offset of k slot (hh, j) within its k-step
+      int64_t idx = -1;
+      const int nfwd = ngp_fwd_count(ne);
+      if (g < nfwd) {
+        int l = 0;
+        for (int i = 1; i < kNgpLayers; ++i)
+          if (g >= ngp_fwd_base(i, ne)) l = i;
+        const int loc = g - ngp_fwd_base(l, ne), nk = ngp_fwd_nk(l, ne);
+        const int o = loc / nk, ks = loc % nk;
+        const int row = 32 * o + r, od = ngp_out_dim(l);
+        int k = -1;
+        if (l == 0) k = (16 * ks + fo < lf) ? 16 * ks + fo : -1;
+        else if (l == 2) k = ks == 0 ? fo : (ks == 1 ? (fo < 8 ? 16 + fo : -1) : kNgpDembDim + fo);
+        else k = 16 * ks + fo;
+        if (row < od && k >= 0) idx = off.w[l] + (int64_t)k * od + row;
+      } else if (g < ngp_total_count(ne)) {
+        int t = 0;
+        for (int i = 1; i < kNgpLayers; ++i)
+          if (g >= ngp_bwd_base(i, ne)) t = i;
+        const int loc = g - ngp_bwd_base(t, ne), nk = ngp_bwd_nk(t);
+        const int o = loc / nk, ks = loc % nk;
+        const int l = 4 - t, od = ngp_out_dim(l);
+        // A[row = input feature of Dense_l][k = output feature of Dense_l] = W_l[row][k]
+        int row = 32 * o + r;
+        const int k = 16 * ks + fo;
+        if (l == 2) row = r < kNgpDensityDim ? kNgpDembDim + r : -1;  // only the rows fed by `out`
+        else if (l == 0) row = r < lf ? r : -1;
+        else if (row >= kNgpHidden) row = -1;
+        if (row >= 0 && k < od) idx = off.w[l] + (int64_t)row * od + k;
+      }
+      reinterpret_cast<__bf16*>(packed)[e] = (__bf16)(idx >= 0 ? params[idx] : 0.0f);
+    } else {
+      const int i = e - total_frag_elems;
+      int l = 0;
+      for (int k = 1; k < kNgpLayers; ++k)
+        if (i >= ngp_bias_base(k)) l = k;
+      const int loc = i - ngp_bias_base(l);
+      reinterpret_cast<float*>(packed + kNgpPackBiasOff)[i] = loc < ngp_out_dim(l) ? params[off.b[l] + loc] : 0.0f;
+    }
+  }
+}
+
+}  // namespace lnrf
+
+using namespace lnrf;
+
+static bool ngp_supported(const lnrf_ngp_mlp_desc* d) {
+  return d && d->hidden_dim == kNgpHidden && d->density_dim == kNgpDensityDim && d->density_layers == 1 &&
+         d->color_layers == 2 && d->d_freqs == 4 && d->enc_dim >= 1 && d->enc_dim <= 32;
+}
+static inline int64_t ngp_tiles(int64_t m) { return (m + kTileCols - 1) / kTileCols; }
+static NgpOffsets ngp_offsets(const lnrf_ngp_mlp_desc* d) {
+  NgpOffsets o;
+  int64_t off = d->dense_offset;
+  int fan[kNgpLayers] = {d->enc_dim, kNgpHidden, kNgpDembDim + kNgpDensityDim, kNgpHidden, kNgpHidden};
+  for (int l = 0; l < kNgpLayers; ++l) {
+    o.w[l] = off;
+    off += (int64_t)fan[l] * ngp_out_dim(l);
+    o.b[l] = off;
+    off += ngp_out_dim(l);
+  }
+  return o;
+}
+#define NGP_REQUIRE_SUPPORTED(fn)                                                                          \
+  if (!ngp_supported(desc)) {                                                                              \
+    set_error(fn ": only InstantNGPModel{hidden 64, density_dim 16, 1 density layer, 2 color layers, "    \
+                 "d_freqs 4, L*F <= 32} is fused");                                                        \
+    return LNRF_ERR_UNSUPPORTED;                                                                           \
+  }
+
+template <class K>
+static int ngp_ensure_lds(K kernel, int bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+  return LNRF_OK;
+}
+
+extern "C" int64_t lnrf_ngp_mlp_packed_bytes(const lnrf_ngp_mlp_desc* desc) {
+  return ngp_supported(desc) ? kNgpPackBytes : -1;
+}
+extern "C" int64_t lnrf_ngp_mlp_scratch_bytes(const lnrf_ngp_mlp_desc* desc, int64_t m) {
+  return ngp_supported(desc) ? (int64_t)kNgpSlots * ngp_tiles(m) * kFragBytes : -1;
+}
+
+extern "C" int lnrf_ngp_mlp_pack(const lnrf_ngp_mlp_desc* desc, const float* params, void* packed,
+                                 lnrf_stream_t stream) {
+  NGP_REQUIRE_SUPPORTED("lnrf_ngp_mlp_pack");
+  LNRF_CHECK_ARG(params && packed, "null pointer");
+  LNRF_CHECK_ARG(desc->dense_offset >= 0, "bad dense_offset");
+  const int ne = desc->enc_dim <= 16 ? 1 : 2;
+  hipLaunchKernelGGL(ngp_pack_kernel, dim3(64), dim3(256), 0, as_stream(stream), params, ngp_offsets(desc),
+                     (int)desc->enc_dim, ne, (char*)packed);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_ngp_mlp_fwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t,
+                                const float* d, int64_t m, float* density, float* rgb, lnrf_stream_t stream) {
+  NGP_REQUIRE_SUPPORTED("lnrf_ngp_mlp_fwd");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(packed && enc_t && d && density && rgb, "null pointer");
+  const int64_t n_tiles = ngp_tiles(m);
+  const dim3 grid((unsigned)((n_tiles + kWaves - 1) / kWaves)), block(kThreads);
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (desc->enc_dim <= 16) {
+    rc = ngp_ensure_lds(ngp_mlp_kernel<1, false>, kNgpLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_kernel<1, false>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
+                       (int)desc->enc_dim, m, n_tiles, density, rgb, nullptr, nullptr, nullptr, nullptr);
+  } else {
+    rc = ngp_ensure_lds(ngp_mlp_kernel<2, false>, kNgpLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_kernel<2, false>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
+                       (int)desc->enc_dim, m, n_tiles, density, rgb, nullptr, nullptr, nullptr, nullptr);
+  }
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t,
+                                const float* d, const float* g_density, const float* g_rgb, int64_t m,
+                                void* scratch, float* g_enc_t, float* grads, lnrf_stream_t stream) {
+  NGP_REQUIRE_SUPPORTED("lnrf_ngp_mlp_bwd");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(packed && enc_t && d && g_density && g_rgb && scratch && g_enc_t && grads, "null pointer");
+  const int64_t n_tiles = ngp_tiles(m);
+  const dim3 grid((unsigned)((n_tiles + kWaves - 1) / kWaves)), block(kThreads);
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (desc->enc_dim <= 16) {
+    rc = ngp_ensure_lds(ngp_mlp_kernel<1, true>, kNgpLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_kernel<1, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
+                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
+  } else {
+    rc = ngp_ensure_lds(ngp_mlp_kernel<2, true>, kNgpLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_kernel<2, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
+                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
+  }
+  LNRF_LAUNCH_CHECK();
+
+  // weight gradients: one launch, five Dense problems
+  const NgpOffsets off = ngp_offsets(desc);
+  const int lf = desc->enc_dim;
+  NgpWgradArgs a;
+  int first = 0;
+  auto add = [&](int i, int shape, int xs, int ys, int layer, int rb0, int rv0, int rb1, int rv1, int rb2, int rv2,
+                 int rb3, int rv3) {
+    NgpWgradProblem p;
+    p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.do_bias = 1;
+    p.out_dim = ngp_out_dim(layer);
+    p.w_lo = (unsigned)(off.w[layer] & 0xFFFFFFFFll); p.w_hi = (unsigned)(off.w[layer] >> 32);
+    p.b_lo = (unsigned)(off.b[layer] & 0xFFFFFFFFll); p.b_hi = (unsigned)(off.b[layer] >> 32);
+    p.rb0 = rb0; p.rv0 = rv0; p.rb1 = rb1; p.rv1 = rv1;
+    p.rb2 = rb2; p.rv2 = rv2; p.rb3 = rb3; p.rv3 = rv3;
+    int64_t nb = 64;
+    const int64_t max_nb = (n_tiles + 2 * kNgpWgSpi - 1) / (2 * kNgpWgSpi);
+    if (nb > max_nb) nb = max_nb;
+    p.first_block = first;
+    p.n_blocks = (int)nb;
+    first += (int)nb;
+    a.p[i] = p;
+  };
+  add(0, 2, kNgpXC1, kNgpDy3, 3, 0, 16, 16, 16, 32, 16, 48, 16);
+  add(1, 2, kNgpXCat, kNgpDy2, 2, 0, 16, 16, 8, kNgpDembDim, 16, 0, 0);
+  add(2, 1, kNgpXH0, kNgpDy1, 1, 0, 16, 16, 16, 32, 16, 48, 16);
+  add(3, 1, kNgpXC2, kNgpDy4, 4, 0, 16, 16, 16, 32, 16, 48, 16);
+  add(4, 0, kNgpXEnc, kNgpDy0, 0, 0, lf < 16 ? lf : 16, 16, lf > 16 ? lf - 16 : 0, 0, 0, 0, 0);
+  rc = ngp_ensure_lds(ngp_wgrad_kernel, kNgpWgradLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ngp_wgrad_kernel, dim3((unsigned)first), dim3(kThreads), kNgpWgradLds, st, a,
+                     (const char*)scratch, n_tiles, grads);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}

@@ -27,6 +27,12 @@ class NerfShape(ctypes.Structure):
                 ("input_layers", "mid_layers", "hidden_dim", "color_layer_dim", "x_freqs", "d_freqs")]
 
 
+class NgpMlpDesc(ctypes.Structure):
+    _fields_ = [("enc_dim", c_int32), ("hidden_dim", c_int32), ("density_dim", c_int32),
+                ("density_layers", c_int32), ("color_layers", c_int32), ("d_freqs", c_int32),
+                ("dense_offset", c_int64)]
+
+
 _P = c_void_p
 _F3 = POINTER(c_float)
 
@@ -79,6 +85,11 @@ PROTOTYPES = {
     "lnrf_nerf_mlp_bwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "lnrf_nerf_mlp_bwd_chain": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "lnrf_nerf_mlp_bwd_weights": (c_int32, [POINTER(NerfShape), _P, _P, c_int64, _P, _P]),
+    "lnrf_ngp_mlp_packed_bytes": (c_int64, [POINTER(NgpMlpDesc)]),
+    "lnrf_ngp_mlp_scratch_bytes": (c_int64, [POINTER(NgpMlpDesc), c_int64]),
+    "lnrf_ngp_mlp_pack": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P]),
+    "lnrf_ngp_mlp_fwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_ngp_mlp_bwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "lnrf_adam_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
                                  c_float, _P]),
     "lnrf_sq_norm": (c_int32, [_P, c_int64, _P, _P]),

@@ -3,11 +3,14 @@ learn_nerf.instant_ngp — InstantNGPModel, MultiresHashTableEncoding, HashTable
 hash_table_lookup (reference: learn_nerf/instant_ngp.py).
 
 The multiresolution hash-grid gather / scatter-add are HIP kernels (csrc/hashgrid.hip, level-major
-sweep so one level's table stays L2-resident); the tiny MLP runs on the exact-fp32 strided GEMM.
+sweep so one level's table stays L2-resident); the tiny MLP is the fused bf16 MFMA kernel of
+csrc/ngp_mlp.hip (precision="bf16", default) or the exact-fp32 strided GEMM (precision="fp32").
 Parameter tree names follow Flax: MultiresHashTableEncoding_0/HashTableEncoding_{l}/table, Dense_0..4.
 """
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Sequence, Tuple
+
+import ctypes
 
 import torch
 
@@ -100,11 +103,84 @@ class InstantNGPModel(ModelBase):
     density_dim: int = 16
     density_layers: int = 1
     color_layers: int = 2
+    precision: str = "bf16"  # "bf16" (fused MFMA MLP, lnrf_ngp_mlp_*) | "fp32" (exact dense path)
     tag: str = "ngp"
+
+    _pack_cache: Any = field(default=None, repr=False, compare=False)
+    _pack_generation: int = field(default=0, repr=False, compare=False)
+
+    def invalidate_packed(self) -> None:
+        """Call after the parameters were modified outside torch (e.g. by lnrf_adam_step)."""
+        self._pack_generation += 1
 
     def encoding(self) -> MultiresHashTableEncoding:
         return MultiresHashTableEncoding(self.table_sizes, self.grid_sizes, self.bbox_min, self.bbox_max,
                                          self.table_feature_dim, self.table_smooth)
+
+    # ---- fused bf16 MLP ---------------------------------------------------------------------------
+    def fused_supported(self) -> bool:
+        return ((self.hidden_dim, self.density_dim, self.density_layers, self.color_layers, self.d_freqs)
+                == (64, 16, 1, 2, 4) and len(self.grid_sizes) * self.table_feature_dim <= 32)
+
+    def _use_fused(self) -> bool:
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError(f"unknown precision {self.precision!r}")
+        return self.precision == "bf16" and self.fused_supported()
+
+    def _mlp_desc(self) -> L.NgpMlpDesc:
+        return L.NgpMlpDesc(len(self.grid_sizes) * self.table_feature_dim, self.hidden_dim, self.density_dim,
+                            self.density_layers, self.color_layers, self.d_freqs,
+                            self.encoding().num_table_floats())
+
+    def packed_weights(self, flat: torch.Tensor) -> torch.Tensor:
+        """bf16 MFMA-fragment copy of the Dense parameters; rebuilt when the flat buffer changes."""
+        key = (flat.data_ptr(), flat._version, flat.device, self._pack_generation)
+        if self._pack_cache is not None and self._pack_cache[0] == key:
+            return self._pack_cache[1]
+        desc = self._mlp_desc()
+        nbytes = L.lib().lnrf_ngp_mlp_packed_bytes(ctypes.byref(desc))
+        packed = (self._pack_cache[1] if self._pack_cache is not None and self._pack_cache[1].device == flat.device
+                  else torch.empty(nbytes, dtype=torch.uint8, device=flat.device))
+        L.check(L.lib().lnrf_ngp_mlp_pack(ctypes.byref(desc), L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
+                "ngp_mlp_pack")
+        self._pack_cache = (key, packed)
+        return packed
+
+    def _fused_forward_points(self, flat, x, d, save: bool):
+        enc = self.encoding()
+        tables, _ = self._dense_views(flat)
+        m, dev = x.shape[0], flat.device
+        desc = self._mlp_desc()
+        packed = self.packed_weights(flat)
+        with _prof.section(f"{self.tag}_hashgrid_fwd"):
+            enc_t = enc.encode_t(tables, x)  # [L*F, M]
+        density = torch.empty(m, dtype=F32, device=dev)
+        rgb = torch.empty((m, 3), dtype=F32, device=dev)
+        d = d.contiguous()
+        with _prof.section(f"{self.tag}_mlp_fwd"):
+            L.check(L.lib().lnrf_ngp_mlp_fwd(ctypes.byref(desc), L.ptr(packed, torch.uint8), L.ptr(enc_t), L.ptr(d),
+                                             m, L.ptr(density), L.ptr(rgb), L.stream()), "ngp_mlp_fwd")
+        ctx = dict(kind="fused", packed=packed, x=x, d=d, enc_t=enc_t) if save else None
+        return density, rgb, {}, ctx
+
+    def _fused_backward(self, ctx, g_density, g_rgb, grad_flat):
+        enc = self.encoding()
+        g_tables, _ = self._dense_views(grad_flat)
+        desc = self._mlp_desc()
+        m, dev = ctx["x"].shape[0], grad_flat.device
+        lf = desc.enc_dim
+        with _prof.section(f"{self.tag}_mlp_bwd"):
+            nbytes = L.lib().lnrf_ngp_mlp_scratch_bytes(ctypes.byref(desc), m)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            g_enc_t = torch.empty((lf, m), dtype=F32, device=dev)
+            gd = g_density.reshape(-1).contiguous()
+            gr = g_rgb.reshape(-1, 3).contiguous()
+            L.check(L.lib().lnrf_ngp_mlp_bwd(
+                ctypes.byref(desc), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["enc_t"]), L.ptr(ctx["d"]),
+                L.ptr(gd), L.ptr(gr), m, L.ptr(scratch, torch.uint8), L.ptr(g_enc_t), L.ptr(grad_flat),
+                L.stream()), "ngp_mlp_bwd")
+        with _prof.section(f"{self.tag}_hashgrid_bwd"):
+            ops.hashgrid_bwd(enc.desc(), ctx["x"], g_enc_t, g_tables)
 
     def dense_dims(self) -> List[Tuple[int, int]]:
         dims, fan = [], len(self.grid_sizes) * self.table_feature_dim
@@ -149,6 +225,8 @@ class InstantNGPModel(ModelBase):
         return flat[:nt], out
 
     def forward_points(self, flat, x, d, save: bool):
+        if self._use_fused():
+            return self._fused_forward_points(flat, x, d, save)
         enc = self.encoding()
         tables, W = self._dense_views(flat)
         m, dev = x.shape[0], flat.device
@@ -188,6 +266,8 @@ class InstantNGPModel(ModelBase):
         return density.view(-1), rgb, {}, ctx
 
     def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+        if ctx.get("kind") == "fused":
+            return self._fused_backward(ctx, g_density, g_rgb, grad_flat)
         enc = self.encoding()
         tables, W = self._dense_views(ctx["flat"])
         g_tables, G = self._dense_views(grad_flat)

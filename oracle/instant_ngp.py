@@ -84,8 +84,11 @@ def ngp_param_count(table_sizes, grid_sizes, feature_dim=2, **kw) -> int:
 
 def ngp_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, table_sizes, grid_sizes, bbox_min, bbox_max,
               feature_dim=2, smooth=False, d_freqs=4, hidden_dim=64, density_dim=16, density_layers=1,
-              color_layers=2):
-    """InstantNGPModel.__call__ (instant_ngp.py:34-54) -> (density[N,1], rgb[N,3], {})."""
+              color_layers=2, operand_round=None):
+    """InstantNGPModel.__call__ (instant_ngp.py:34-54) -> (density[N,1], rgb[N,3], {}).
+    ``operand_round`` (e.g. oracle.model.bf16_round) is applied to both operands of every Dense matmul; it
+    models the bf16-operand / fp32-accumulate arithmetic of the fused MFMA kernel, nothing else changes."""
+    rnd = operand_round if operand_round is not None else (lambda t: t)
     rows, dims = ngp_spec(table_sizes, grid_sizes, feature_dim, d_freqs, hidden_dim, density_dim, density_layers,
                           color_layers)
     off = 0
@@ -108,16 +111,16 @@ def ngp_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, table_sizes,
     d_emb = sinusoidal_emb(d, d_freqs)  # :37
     li = 0
     for _ in range(density_layers):  # :46-47
-        out = torch.relu(out @ layers[li][0] + layers[li][1])
+        out = torch.relu(rnd(out) @ rnd(layers[li][0]) + layers[li][1])
         li += 1
-    out = out @ layers[li][0] + layers[li][1]  # :48
+    out = rnd(out) @ rnd(layers[li][0]) + layers[li][1]  # :48
     li += 1
     density = torch.exp(out[:, :1])  # :49 (unclamped)
     out = torch.cat([d_emb, out], dim=1)  # :50 (d_emb first)
     for _ in range(color_layers):  # :51-52
-        out = torch.relu(out @ layers[li][0] + layers[li][1])
+        out = torch.relu(rnd(out) @ rnd(layers[li][0]) + layers[li][1])
         li += 1
-    color = torch.tanh(out @ layers[li][0] + layers[li][1])  # :53
+    color = torch.tanh(rnd(out) @ rnd(layers[li][0]) + layers[li][1])  # :53
     return density, color, {}
 
 

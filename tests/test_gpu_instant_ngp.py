@@ -54,11 +54,11 @@ def test_hashgrid_fwd_bwd(cfg, smooth):
     assert err < 2e-4 * max(1.0, g_ref.abs().max().item())
 
 
-def make_model(levels, table, hidden=64, seed=2):
+def make_model(levels, table, hidden=64, seed=2, precision="fp32"):
     from learn_nerf.instant_ngp import InstantNGPModel
 
     model = InstantNGPModel(table_sizes=[table] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)],
-                            bbox_min=BMIN, bbox_max=BMAX, hidden_dim=hidden)
+                            bbox_min=BMIN, bbox_max=BMAX, hidden_dim=hidden, precision=precision)
     params = model.init(dict(params=seed))["params"]
     flat = model.flat(params)
     nt = model.encoding().num_table_floats()
@@ -102,14 +102,77 @@ def test_ngp_model_forward_backward(levels, table):
         assert rel < 2e-2
 
 
-def test_ngp_train_step_matches_oracle():
+@pytest.mark.parametrize("levels,table,m", [(6, 2 ** 12, 2500), (16, 2 ** 14, 4133), (3, 2 ** 10, 31)])
+def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m):
+    """
+    lnrf_ngp_mlp_fwd / lnrf_ngp_mlp_bwd (bf16 MFMA operands, fp32 accumulate) against the oracle with the same
+    operand rounding.  Forward: 2e-3 (bf16 rounding boundaries of intermediate activations); gradients: 3e-2
+    relative L2 (ReLU mask flips + bf16 dy operands), as for the fused NeRFModel.  The distance to the exact
+    float64 model is printed.  m = 4133 / 31 exercise ragged tiles and partially filled workgroups.
+    """
+    from oracle.model import bf16_round
+
+    model, params, flat = make_model(levels, table, precision="bf16")
+    assert model._use_fused()
+    x, d, gen = points(m, seed=levels)
+    _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+    dens, rgb, _, _ = model.forward_points(flat, x.cuda(), d.cuda(), save=False)
+    assert ctx["kind"] == "fused"
+    f32 = flat.cpu().float().requires_grad_(True)
+    rd, rr, _ = ON.ngp_model(f32, x, d, model.table_sizes, model.grid_sizes, BMIN, BMAX, operand_round=bf16_round)
+    ed, er, _ = ON.ngp_model(flat.cpu().double(), x.double(), d.double(), model.table_sizes, model.grid_sizes, BMIN, BMAX)
+    e_rgb = (rgb.cpu() - rr).abs().max().item()
+    e_den = ((dens.cpu() - rd[:, 0]).abs() / (1 + rd[:, 0].abs())).max().item()
+    x_rgb = (rgb.cpu().double() - er).abs().max().item()
+    print(f"L={levels} m={m}: fused vs bf16 oracle rgb {e_rgb:.2e} density {e_den:.2e}; vs exact rgb {x_rgb:.2e}")
+    assert e_rgb < 2e-3 and e_den < 2e-3
+    assert x_rgb < 3e-2
+    g_d = torch.randn(m, generator=gen).float()
+    g_c = torch.randn(m, 3, generator=gen).float()
+    (g_ref,) = torch.autograd.grad((rd[:, 0] * g_d).sum() + (rr * g_c).sum(), f32)
+    grad = torch.zeros_like(flat)
+    model.backward(ctx, g_d.cuda(), g_c.cuda(), None, grad)
+    nt = model.encoding().num_table_floats()
+    got = grad.cpu()
+    for name, a, b in (("tables", got[:nt], g_ref[:nt]), ("mlp", got[nt:], g_ref[nt:])):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"   {name}: rel L2 err vs bf16-operand oracle {rel:.2e}")
+        assert rel < 3e-2, (name, rel)
+    # per-layer check so that a misplaced block cannot hide in the norm of a larger one
+    off = nt
+    for i, (fi, fo) in enumerate(model.dense_dims()):
+        for kind, n in (("kernel", fi * fo), ("bias", fo)):
+            a, b = got[off:off + n], g_ref[off:off + n]
+            rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+            assert rel < 6e-2, (f"Dense_{i}/{kind}", rel)
+            off += n
+    # a second backward into the same buffer accumulates
+    model.backward(ctx, g_d.cuda(), g_c.cuda(), None, grad)
+    assert ((grad.cpu() - 2 * got).norm() / got.norm()).item() < 1e-3
+
+
+def test_ngp_fused_unsupported_shape_uses_dense_path():
+    model, params, flat = make_model(4, 2 ** 10, hidden=32, precision="bf16")
+    assert not model._use_fused()
+    x, d, _ = points(100)
+    dens, rgb, _ = model.apply(dict(params=params), x.cuda(), d.cuda())
+    rd, rr, _ = ON.ngp_model(flat.cpu().double(), x.double(), d.double(), model.table_sizes, model.grid_sizes, BMIN,
+                             BMAX, hidden_dim=32)
+    assert (rgb.cpu().double() - rr).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_ngp_train_step_matches_oracle(precision):
     from learn_nerf.instant_ngp import InstantNGPModel
     from learn_nerf.rng import Key, split
     from learn_nerf.train import TrainLoop
+    from oracle.model import bf16_round
+
+    rnd = bf16_round if precision == "bf16" else None
 
     def mk(levels):
         return InstantNGPModel(table_sizes=[2 ** 12] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)],
-                               bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3)
+                               bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3, precision=precision)
 
     n, tc, tf, lr = 128, 16, 32, 1e-2
     loop = TrainLoop(mk(3), mk(5), init_rng=4, lr=lr, coarse_ts=tc, fine_ts=tf, adam_eps=1e-15, adam_b1=0.9,
@@ -131,7 +194,8 @@ def test_ngp_train_step_matches_oracle():
     uf = torch.from_numpy(philox.ray_uniforms(fk.seed, 1, 0, n, tf)).double()
 
     def make_fn(model, fl):
-        return lambda x, d: ON.ngp_model(fl, x, d, model.table_sizes, model.grid_sizes, (-1.0,) * 3, (1.0,) * 3)
+        return lambda x, d: ON.ngp_model(fl, x, d, model.table_sizes, model.grid_sizes, (-1.0,) * 3, (1.0,) * 3,
+                                         operand_round=rnd)
 
     params = [cf.clone().requires_grad_(True), ff.clone().requires_grad_(True), bg.clone().requires_grad_(True)]
     total, ld, _ = OT.losses(make_fn(loop.coarse, params[0]), make_fn(loop.fine, params[1]), params[2],
@@ -142,9 +206,12 @@ def test_ngp_train_step_matches_oracle():
     rel = ((loop.grad.cpu().double() - ref_grad).norm() / ref_grad.norm()).item()
     print(f"ngp step: coarse {float(log['coarse']):.6f}/{float(ld['coarse']):.6f} fine {float(log['fine']):.6f}/"
           f"{float(ld['fine']):.6f} grad rel err {rel:.2e}")
-    assert abs(float(log["coarse"]) - float(ld["coarse"])) < 1e-5
-    assert abs(float(log["fine"]) - float(ld["fine"])) < 1e-5
-    assert rel < 5e-3
+    loss_tol, grad_tol = (1e-5, 5e-3) if precision == "fp32" else (2e-4, 3e-2)
+    assert abs(float(log["coarse"]) - float(ld["coarse"])) < loss_tol
+    assert abs(float(log["fine"]) - float(ld["fine"])) < loss_tol
+    assert rel < grad_tol
+    if precision == "bf16":
+        return  # the Adam update itself is covered by the fp32 case
     new = [OT.adam_update(p.detach(), g, torch.zeros_like(g), torch.zeros_like(g), 1, lr, 0.9, 0.99, 1e-15)[0]
            for p, g in zip(params, grads)]
     upd = (loop.flat.cpu().double() - torch.cat([t.reshape(-1) for t in new])).abs()
