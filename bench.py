@@ -134,7 +134,7 @@ def main():
         def ngp(levels):  # scripts/train_nerf.py:150-161 with the table size of BASELINE configs[2]
             return InstantNGPModel(table_sizes=[2 ** args.table_log2] * levels,
                                    grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], bbox_min=BBOX_MIN,
-                                   bbox_max=BBOX_MAX)
+                                   bbox_max=BBOX_MAX, precision=args.precision)
 
         loop = TrainLoop(ngp(6), ngp(16), init_rng=0, lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, adam_eps=1e-15,
                          adam_b1=0.9, adam_b2=0.99, device=device)
@@ -234,7 +234,7 @@ def main():
             metric="ray-samples/s (NeRF train step: fwd + bwd + Adam, 4096 rays x 192 samples per GPU)",
             value=value, unit="ray-samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
-            dtype=("bf16" if args.precision == "bf16" else "f32") if args.workload == "nerf" else "f32",
+            dtype="bf16" if args.precision == "bf16" else "f32",
             data="synthetic",
             config=dict(workload="vanilla NeRF coarse64+fine128 train step (BASELINE.json configs[1])"
                         if args.workload == "nerf" else
@@ -249,6 +249,8 @@ def main():
             kernels=fams,
             losses={k: round(float(v), 5) for k, v in log.items()},
         )
+        if args.workload != "nerf":
+            del out["step_mfma"]  # the FLOP model is the vanilla NeRFModel's; the hash-grid step is gather/scatter bound
         if args.workload == "nerf" and args.precision == "bf16":
             # the same fused MLP kernel without the activation dumps (what render_nerf.py runs): compute-bound
             from learn_nerf import ops as _ops

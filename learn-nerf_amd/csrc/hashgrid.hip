@@ -67,7 +67,11 @@ __device__ __forceinline__ void corner_weight_grad(const Corner& k, int xo, int 
 }
 
 __device__ __forceinline__ unsigned entry_index(unsigned cx, unsigned cy, unsigned cz, int G, int T, int hashed) {
-  if (hashed) return (cx ^ (19349663u * cy) ^ (83492791u * cz)) % (unsigned)T;  // instant_ngp.py:219-223
+  if (hashed) {                                                                  // instant_ngp.py:219-223
+    const unsigned hv = cx ^ (19349663u * cy) ^ (83492791u * cz);
+    // power-of-two tables (the usual case): a mask instead of the ~35-instruction runtime modulo (uniform branch)
+    return (T & (T - 1)) == 0 ? (hv & (unsigned)(T - 1)) : hv % (unsigned)T;
+  }
   return cx + (unsigned)G * (cy + (unsigned)G * cz);                            // :199-201
 }
 
@@ -253,33 +257,60 @@ __global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Bucketed scatter for the hashed levels (every sample touches 8 effectively random entries, so neither
-// LDS pre-reduction per workgroup nor memory-side atomics are efficient).  Pass A bins the 8 (entry,
-// w*g0, w*g1) contributions of every sample by 8K-entry table slice: a workgroup counts its chunk per slice
-// in LDS, reserves room in each slice's global bucket with ONE atomic per (workgroup, slice), and writes its
-// tuples there.  Pass B gives every (level, slice) bucket to exactly one workgroup, which accumulates the
-// bucket in LDS and adds the slice to the gradient table with plain read-modify-write: no global float atomics.
-// Buckets are sized 1.25x the mean (the hash spreads samples evenly); overflowing tuples fall back to atomics.
+// Bucketed scatter.  LDS float atomics are slow on gfx950 (ds_add_f32: ~0.3 lanes/clk/CU, measured with
+// tools/lds_atomic_bench.hip; ds_add_u64: ~5.6) and memory-side float atomics slower still, so the gradient
+// table is reduced with 64-bit INTEGER LDS atomics on fixed-point values:
+// Pass A bins the 8 (entry, w*g0, w*g1) contributions of every sample by 4K-entry table slice: a workgroup
+// counts its chunk per slice in LDS, reserves room in each slice's global bucket with ONE atomic per
+// (workgroup, slice), writes its tuples there and records the level's max |value|.
+// Pass B gives every (level, slice) bucket to one workgroup (few-slice levels: several), which converts the
+// values to fixed point with the power-of-two scale that maps the level's max to 2^44 (exact products, 2^19
+// terms of headroom, resolution 2^-44 of the max), accumulates them with ds_add_u64 and adds the slice to
+// the gradient table.  Integer accumulation is order-independent, so unsplit slices are bit-reproducible.
+// Buckets are sized 1.25x the mean for hashed levels (the hash spreads samples evenly), 4x for dense levels;
+// overflowing tuples fall back to global atomics.
 struct BucketTuple {
-  unsigned rel;  // entry index within the slice
+  unsigned rel;  // entry index within the 4K-entry slice
   float v0, v1;
 };
 constexpr int kBinChunk = 2048;  // samples per binning workgroup
-constexpr int kMaxSlices = 128;  // table <= 1M entries
+constexpr int kBucketEntries = 4096;  // 64 KiB of int64 x 2 features
+constexpr int kMaxSlices = 256;       // table <= 1M entries
+constexpr int kFixedBits = 44;
 
 struct BucketPlan {
   int n;                 // bucketed levels
   int level[kMaxLevels];
   int slices[kMaxLevels];
+  int split[kMaxLevels];             // reduce workgroups per bucket
+  int wg_off[kMaxLevels + 1];        // first reduce workgroup of the level
   long long tuple_off[kMaxLevels];   // first tuple of the level's buckets
   long long cursor_off[kMaxLevels];  // first cursor of the level
-  long long cap;                     // tuples per bucket (same for all: slices differ only via table size)
+  long long cap[kMaxLevels];         // tuples per bucket of the level
 };
+
+// One slot per valid lane in counter[b] with one LDS atomic per RUN of equal b in neighbouring lanes
+// (neighbouring lanes = neighbouring samples of a ray: on dense levels they share the slice, and same-address
+// LDS atomics serialise at ~0.5 lanes/clk).  Must be called by the whole wave.  Returns the lane's offset.
+__device__ __forceinline__ unsigned run_reserve(unsigned* counter, unsigned b, bool valid) {
+  const int lane = threadIdx.x & 63;
+  const unsigned bb = valid ? b : 0xFFFFFFFFu;
+  const unsigned prev = __shfl_up(bb, 1, 64);
+  const bool head = lane == 0 || bb != prev;
+  const unsigned long long heads = __ballot(head);
+  const int hl = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));  // head lane of my run
+  const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+  const int len = above ? __ffsll((long long)above) : 64 - lane;              // run length (head lanes)
+  unsigned base = 0u;
+  if (head && valid) base = atomicAdd(&counter[bb], (unsigned)len);
+  base = __shfl(base, hl, 64);
+  return base + (unsigned)(lane - hl);
+}
 
 __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float* __restrict__ x,
                                     const float* __restrict__ u, int64_t M, const float* __restrict__ g_enc_t,
                                     BucketTuple* __restrict__ tuples, unsigned* __restrict__ cursors,
-                                    float* __restrict__ g_tables) {
+                                    unsigned* __restrict__ level_max, float* __restrict__ g_tables) {
   __shared__ unsigned s_count[kMaxSlices];
   __shared__ unsigned s_base[kMaxSlices];
   const int li = blockIdx.y;
@@ -288,19 +319,22 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
   const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
   BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li];
   unsigned* __restrict__ cur = cursors + plan.cursor_off[li];
-  const long long cap = plan.cap;
+  const long long cap = plan.cap[li];
   for (int i = threadIdx.x; i < S; i += blockDim.x) s_count[i] = 0u;
   __syncthreads();
   const int64_t m0 = (int64_t)blockIdx.x * kBinChunk;
-  const int64_t m1 = m0 + kBinChunk < M ? m0 + kBinChunk : M;
+  constexpr int kIters = kBinChunk / 256;  // blockDim.x == 256; uniform trip count (run_reserve needs the whole wave)
   // pass 1: count per slice
-  for (int64_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+  for (int it = 0; it < kIters; ++it) {
+    const int64_t m = m0 + it * 256 + threadIdx.x;
+    const bool valid = m < M;
+    const int64_t mm = valid ? m : M - 1;
+    const float p[3] = {x[mm * 3 + 0], x[mm * 3 + 1], x[mm * 3 + 2]};
     const Corner k = locate(p, d, G);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const unsigned idx = entry_index(k.base[0] + (c >> 2), k.base[1] + ((c >> 1) & 1), k.base[2] + (c & 1), G, T, hashed);
-      atomicAdd(&s_count[idx / kSliceEntries], 1u);
+      run_reserve(s_count, idx / kBucketEntries, valid);
     }
   }
   __syncthreads();
@@ -311,11 +345,15 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
   }
   __syncthreads();
   // pass 2: write the tuples
-  for (int64_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+  float vmax = 0.0f;
+  for (int it = 0; it < kIters; ++it) {
+    const int64_t m = m0 + it * 256 + threadIdx.x;
+    const bool valid = m < M;
+    const int64_t mm = valid ? m : M - 1;
+    const float p[3] = {x[mm * 3 + 0], x[mm * 3 + 1], x[mm * 3 + 2]};
     const Corner k = locate(p, d, G);
-    const float g0 = g_enc_t[(int64_t)(2 * level) * M + m];
-    const float g1 = g_enc_t[(int64_t)(2 * level + 1) * M + m];
+    const float g0 = valid ? g_enc_t[(int64_t)(2 * level) * M + mm] : 0.0f;
+    const float g1 = valid ? g_enc_t[(int64_t)(2 * level + 1) * M + mm] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int xo = c >> 2, yo = (c >> 1) & 1, zo = c & 1;
@@ -323,53 +361,95 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
       if (u) {
         float gw[3];
         corner_weight_grad(k, xo, yo, zo, gw);
-        w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
+        w = gw[0] * u[mm * 3] + gw[1] * u[mm * 3 + 1] + gw[2] * u[mm * 3 + 2];
       } else {
         w = corner_weight(k, xo, yo, zo);
       }
       const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
-      const unsigned b = idx / kSliceEntries;
-      const long long pos = (long long)s_base[b] + atomicAdd(&s_count[b], 1u);
-      if (pos < cap) {
-        BucketTuple t;
-        t.rel = idx - b * kSliceEntries;
-        t.v0 = w * g0;
-        t.v1 = w * g1;
-        tup[(long long)b * cap + pos] = t;
-      } else {  // bucket full: rare, stay correct
-        float* gt = g_tables + d.table_offset[level] + 2 * (int64_t)idx;
-        atomicAdd(gt, w * g0);
-        atomicAdd(gt + 1, w * g1);
+      const unsigned b = idx / kBucketEntries;
+      const unsigned off = run_reserve(s_count, b, valid);
+      if (valid) {
+        const long long pos = (long long)s_base[b] + off;
+        vmax = fmaxf(vmax, fmaxf(fabsf(w * g0), fabsf(w * g1)));
+        if (pos < cap) {
+          BucketTuple t;
+          t.rel = idx - b * kBucketEntries;
+          t.v0 = w * g0;
+          t.v1 = w * g1;
+          tup[(long long)b * cap + pos] = t;
+        } else {  // bucket full: rare, stay correct
+          float* gt = g_tables + d.table_offset[level] + 2 * (int64_t)idx;
+          atomicAdd(gt, w * g0);
+          atomicAdd(gt + 1, w * g1);
+        }
       }
     }
   }
+  // level max |value| (fixed-point scale of pass B): non-negative floats order like their bit patterns
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[li], __float_as_uint(vmax));
 }
 
-__global__ void hashgrid_reduce_kernel(HashGridDesc d, BucketPlan plan, const BucketTuple* __restrict__ tuples,
-                                       const unsigned* __restrict__ cursors, float* __restrict__ g_tables) {
-  extern __shared__ __attribute__((aligned(16))) float lds_tab[];
-  const int li = blockIdx.y;
+// Pass B.  A bucket is split among plan.split[level] workgroups (few-slice levels would otherwise leave
+// most of the chip idle; their partial slices are flushed with atomics); blockIdx.x -> (level, bucket, part).
+// The tuple stream is read kReduceUnroll tuples per thread ahead of the LDS atomics that consume it.
+constexpr int kReduceThreads = 512;
+constexpr int kReduceUnroll = 4;
+__global__ __launch_bounds__(kReduceThreads) void hashgrid_reduce_kernel(
+    HashGridDesc d, BucketPlan plan, const BucketTuple* __restrict__ tuples, const unsigned* __restrict__ cursors,
+    const unsigned* __restrict__ level_max, float* __restrict__ g_tables) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_q[];
+  int li = 0;
+#pragma unroll 1
+  for (int i = 1; i < plan.n; ++i)
+    if ((int)blockIdx.x >= plan.wg_off[i]) li = i;
   const int level = plan.level[li];
-  const int b = blockIdx.x;
-  if (b >= plan.slices[li]) return;
+  const int split = plan.split[li];
+  const int local = (int)blockIdx.x - plan.wg_off[li];
+  const int b = local / split, part = local - b * split;
   const int T = d.table_size[level];
-  for (int i = threadIdx.x; i < kSliceEntries * 2; i += blockDim.x) lds_tab[i] = 0.0f;
+  for (int i = threadIdx.x; i < kBucketEntries * 2; i += kReduceThreads) lds_q[i] = 0ull;
   __syncthreads();
+  // power-of-two scale: level max < 2^e  ->  values < 2^kFixedBits
+  int e = 0;
+  frexpf(__uint_as_float(level_max[li]), &e);
+  const double scale = ldexp(1.0, kFixedBits - e), inv_scale = ldexp(1.0, e - kFixedBits);
   long long count = cursors[plan.cursor_off[li] + b];
-  if (count > plan.cap) count = plan.cap;
-  const BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li] + (long long)b * plan.cap;
-  for (long long i = threadIdx.x; i < count; i += blockDim.x) {
-    const BucketTuple t = tup[i];
-    atomicAdd(&lds_tab[2 * t.rel], t.v0);
-    atomicAdd(&lds_tab[2 * t.rel + 1], t.v1);
+  if (count > plan.cap[li]) count = plan.cap[li];
+  const long long lo = count * part / split, hi = count * (part + 1) / split;
+  const BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li] + (long long)b * plan.cap[li];
+  for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += (long long)kReduceUnroll * kReduceThreads) {
+    BucketTuple t[kReduceUnroll];
+    // branch-free: out-of-range slots re-read the last tuple and add zeros (a guarded load makes the
+    // compiler wait for every load separately)
+#pragma unroll
+    for (int q = 0; q < kReduceUnroll; ++q) {
+      const long long i = i0 + (long long)q * kReduceThreads;
+      const bool ok = i < hi;
+      t[q] = tup[ok ? i : hi - 1];
+      t[q].v0 = ok ? t[q].v0 : 0.0f;
+      t[q].v1 = ok ? t[q].v1 : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kReduceUnroll; ++q) {
+      const long long q0 = __double2ll_rn((double)t[q].v0 * scale);
+      const long long q1 = __double2ll_rn((double)t[q].v1 * scale);
+      atomicAdd(&lds_q[2 * t[q].rel], (unsigned long long)q0);
+      atomicAdd(&lds_q[2 * t[q].rel + 1], (unsigned long long)q1);
+    }
   }
   __syncthreads();
-  const long long slice0 = (long long)b * kSliceEntries;
-  const int n = (int)((T - slice0 < kSliceEntries ? T - slice0 : kSliceEntries) * 2);
+  const long long slice0 = (long long)b * kBucketEntries;
+  const int n = (int)((T - slice0 < kBucketEntries ? T - slice0 : kBucketEntries) * 2);
   float* __restrict__ gt = g_tables + d.table_offset[level] + 2 * slice0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = lds_tab[i];
-    if (v != 0.0f) gt[i] += v;  // this workgroup is the only writer of the slice in this launch
+  for (int i = threadIdx.x; i < n; i += kReduceThreads) {
+    const long long q = (long long)lds_q[i];
+    if (q != 0) {
+      const float v = (float)((double)q * inv_scale);
+      if (split == 1) gt[i] += v;  // this workgroup is the only writer of the slice in this launch
+      else atomicAdd(gt + i, v);
+    }
   }
 }
 
@@ -435,33 +515,39 @@ extern "C" int lnrf_hashgrid_input_grad(const lnrf_hashgrid_desc* desc, const fl
   return LNRF_OK;
 }
 
-static bool level_is_bucketed(const HashGridDesc& d, int l) {
-  const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
-  return d.hashed[l] && slices >= 16 && slices <= kMaxSlices;
-}
+// Every level whose table has at most kMaxSlices 4K-entry slices is bucketed (hashed or dense).
+static int bucket_slices(const HashGridDesc& d, int l) { return (d.table_size[l] + kBucketEntries - 1) / kBucketEntries; }
+static bool level_is_bucketed(const HashGridDesc& d, int l) { return bucket_slices(d, l) <= kMaxSlices; }
 static BucketPlan make_plan(const HashGridDesc& d, int64_t m, int64_t* tuple_total, int64_t* cursor_total) {
   BucketPlan p;
   p.n = 0;
   int64_t toff = 0, coff = 0;
-  int min_slices = kMaxSlices;
-  for (int l = 0; l < d.n_levels; ++l)
-    if (level_is_bucketed(d, l)) {
-      const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
-      if (slices < min_slices) min_slices = slices;
-    }
-  // one capacity for all buckets: 1.25x the mean of the level with the fewest slices, plus slack
-  p.cap = (long long)((double)m * 8.0 / (double)min_slices * 1.25) + 4096;
+  int wg = 0;
   for (int l = 0; l < d.n_levels; ++l) {
     if (!level_is_bucketed(d, l)) continue;
-    const int slices = (d.table_size[l] + kSliceEntries - 1) / kSliceEntries;
+    const int slices = bucket_slices(d, l);
+    // capacity: the hash spreads samples evenly (1.25x the mean); dense levels follow the scene geometry
+    // (4x the mean).  Overflowing tuples fall back to atomics in the bin kernel.
+    const double mean = (double)m * 8.0 / (double)slices;
+    long long cap = (long long)(mean * (d.hashed[l] ? 1.25 : 4.0)) + 4096;
+    if (cap > m * 8) cap = m * 8;
+    // One workgroup streams about 1 tuple/ns, so buckets of more than ~64K tuples (few-slice levels) are
+    // split; a split bucket is flushed with (contiguous) atomics, an unsplit one with plain stores.
+    int split = mean <= 81920.0 ? 1 : (int)((mean + 65535.0) / 65536.0);
+    if (split > 64) split = 64;
     p.level[p.n] = l;
     p.slices[p.n] = slices;
+    p.split[p.n] = split;
+    p.wg_off[p.n] = wg;
+    p.cap[p.n] = cap;
     p.tuple_off[p.n] = toff;
     p.cursor_off[p.n] = coff;
-    toff += (int64_t)slices * p.cap;
+    wg += slices * split;
+    toff += (int64_t)slices * cap;
     coff += slices;
     ++p.n;
   }
+  p.wg_off[p.n] = wg;
   *tuple_total = toff;
   *cursor_total = coff;
   return p;
@@ -473,7 +559,7 @@ extern "C" int64_t lnrf_hashgrid_bwd_scratch_bytes(const lnrf_hashgrid_desc* des
   memcpy((void*)&d, (const void*)desc, sizeof(d));
   int64_t tuples = 0, cursors = 0;
   make_plan(d, m, &tuples, &cursors);
-  return ((cursors * 4 + 255) / 256) * 256 + tuples * (int64_t)sizeof(BucketTuple);
+  return (((cursors + kMaxLevels) * 4 + 255) / 256) * 256 + tuples * (int64_t)sizeof(BucketTuple);
 }
 
 extern "C" int lnrf_hashgrid_bwd_dir(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
@@ -491,25 +577,24 @@ extern "C" int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const 
   if (m == 0) return LNRF_OK;
   HashGridDesc d;
   memcpy((void*)&d, (const void*)desc, sizeof(d));
-  // hashed levels with >= 16 slices go to the bucketed path when the caller provides scratch memory
+  // bucketed path when the caller provides scratch memory; without it: LDS-sliced / direct atomic kernels
   int64_t tuple_total = 0, cursor_total = 0;
   const BucketPlan plan = make_plan(d, m, &tuple_total, &cursor_total);
-  const int64_t cursor_bytes = ((cursor_total * 4 + 255) / 256) * 256;
+  const int64_t cursor_bytes = (((cursor_total + kMaxLevels) * 4 + 255) / 256) * 256;  // cursors + level max
   const bool use_buckets = scratch && plan.n > 0 &&
                            scratch_bytes >= cursor_bytes + tuple_total * (int64_t)sizeof(BucketTuple);
   if (use_buckets) {
     unsigned* cursors = reinterpret_cast<unsigned*>(scratch);
+    unsigned* level_max = cursors + cursor_total;
     BucketTuple* tuples = reinterpret_cast<BucketTuple*>(reinterpret_cast<char*>(scratch) + cursor_bytes);
     hipError_t e = hipMemsetAsync(cursors, 0, (size_t)cursor_bytes, as_stream(stream));
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(bucket cursors)");
     const unsigned chunks = (unsigned)((m + kBinChunk - 1) / kBinChunk);
     hipLaunchKernelGGL(hashgrid_bin_kernel, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d, plan, x,
-                       u, m, g_enc_t, tuples, cursors, g_tables);
+                       u, m, g_enc_t, tuples, cursors, level_max, g_tables);
     LNRF_LAUNCH_CHECK();
-    int max_s = 0;
-    for (int i = 0; i < plan.n; ++i) max_s = plan.slices[i] > max_s ? plan.slices[i] : max_s;
-    hipLaunchKernelGGL(hashgrid_reduce_kernel, dim3((unsigned)max_s, (unsigned)plan.n), dim3(256), 64 * 1024,
-                       as_stream(stream), d, plan, tuples, cursors, g_tables);
+    hipLaunchKernelGGL(hashgrid_reduce_kernel, dim3((unsigned)plan.wg_off[plan.n]), dim3(kReduceThreads), 64 * 1024,
+                       as_stream(stream), d, plan, tuples, cursors, level_max, g_tables);
     LNRF_LAUNCH_CHECK();
   }
   // levels with 8K < entries <= 512K go to the sliced LDS kernel, the rest to the direct kernel

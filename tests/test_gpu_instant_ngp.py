@@ -261,28 +261,39 @@ def test_ngp_ref_nerf_forward_backward(levels, table):
         assert rel < 5e-3, (name, rel)
 
 
-def test_bucketed_scatter_matches_direct_path():
-    """Hashed levels with >= 16 table slices use the bucketed (atomic-free) reduction; same result as the
-    LDS-sliced / atomic kernels, for value weights and for derivative weights."""
+@pytest.mark.parametrize("clustered", [False, True])
+def test_bucketed_scatter_matches_direct_path(clustered):
+    """Levels with 4..128 table slices (dense 32^3 / 48^3 and hashed 128^3 / 512^3 here) use the bucketed
+    reduction; same result as the LDS-sliced / atomic kernels, for value weights and for derivative weights.
+    clustered: all samples in 2 % of the box, so the dense levels overflow their bucket capacity and exercise
+    the atomic fallback of the bin kernel."""
     import ctypes
 
     from learn_nerf import _lib as L
     from learn_nerf import ops
     from learn_nerf.instant_ngp import MultiresHashTableEncoding
 
-    enc = MultiresHashTableEncoding([2 ** 17] * 3, [16, 128, 512], BMIN, BMAX, 2, True)
+    grids = [16, 32, 48, 128, 512]
+    enc = MultiresHashTableEncoding([2 ** 17] * len(grids), grids, BMIN, BMAX, 2, True)
     desc = enc.desc()
     m = 20000
     x, _, gen = points(m, seed=11)
-    g = torch.randn(6, m, generator=gen).float().cuda()
+    if clustered:
+        lo, hi = torch.tensor(BMIN), torch.tensor(BMAX)
+        x = (lo + (hi - lo) * (0.4 + 0.02 * torch.rand(m, 3, generator=gen))).float().contiguous()
+    g = torch.randn(2 * len(grids), m, generator=gen).float().cuda()
     u = torch.randn(m, 3, generator=gen).float().cuda()
-    assert L.lib().lnrf_hashgrid_bwd_scratch_bytes(ctypes.byref(desc), m) > 2 * 16 * 20000 * 8 * 12 // 16
+    assert L.lib().lnrf_hashgrid_bwd_scratch_bytes(ctypes.byref(desc), m) > 4 * 20000 * 8 * 12
     for uu in (None, u):
         a = torch.zeros(enc.num_table_floats(), device="cuda")
         b = torch.zeros_like(a)
-        ops.hashgrid_bwd(desc, x.cuda(), g, a, u=uu)  # bucketed for the two hashed levels
+        ops.hashgrid_bwd(desc, x.cuda(), g, a, u=uu)  # bucketed for all but the 16^3 level
         L.check(L.lib().lnrf_hashgrid_bwd_bucketed(ctypes.byref(desc), L.ptr(x.cuda()), L.ptr(uu), m, L.ptr(g),
                                                    L.ptr(b), None, 0, L.stream()))  # no scratch: direct kernels
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() < 1e-5 * scale
         assert a.abs().sum().item() > 0
+        off = 0
+        for r in enc.rows():  # every level contributes
+            assert a[off:off + 2 * r].abs().sum().item() > 0
+            off += 2 * r
