@@ -178,3 +178,17 @@ def ray_t_range(bbox: torch.Tensor, ray: torch.Tensor, min_t_range: float = 1e-3
     ts = torch.stack([t_min, t_max], dim=-1)
     mask = mask.bool()
     return (ts[0], mask[0]) if single else (ts, mask)
+
+
+def z_depth(coords: torch.Tensor, alphas: torch.Tensor, camera_origin, camera_direction,
+            max_depth: float) -> torch.Tensor:
+    """
+    Normalised z-depth of the expected collision point (scripts/render_new_dataset.py:96-116): for rays that
+    hit with probability > 0.9, ((coords - origin) . direction) / (alpha + 1e-8) clipped to [0, max_depth];
+    max_depth otherwise; divided by max_depth.  coords [N,3] is the alpha-weighted mean point, alphas [N,1].
+    """
+    origin = torch.as_tensor(camera_origin, dtype=coords.dtype, device=coords.device)
+    direction = torch.as_tensor(camera_direction, dtype=coords.dtype, device=coords.device)
+    along = ((coords - origin) * direction).sum(dim=-1, keepdim=True) / (alphas + 1e-8)
+    depth = torch.where(alphas > 0.9, along, torch.full_like(along, max_depth))
+    return depth.clamp(0.0, max_depth) / max_depth

@@ -210,3 +210,35 @@ def test_blender_converter_and_loader_roundtrip(tmp_path):
     assert v.rays().shape == (32, 3, 3)
     with pytest.raises(FileExistsError):
         convert_blender.convert(str(src), str(out))
+
+
+def test_z_depth_and_random_view_match_reference_formulas():
+    """scripts/render_new_dataset.py:78-116 restated with NumPy: z-depth normalisation and the pose sampler."""
+    import numpy as np
+    import torch
+
+    from learn_nerf.render import z_depth
+    from learn_nerf.scripts.render_new_dataset import random_view
+
+    gen = np.random.RandomState(0)
+    n, max_depth = 200, 7.0
+    coords = gen.normal(size=(n, 3)).astype(np.float32) * 3
+    alphas = gen.uniform(0.5, 1.0, size=(n, 1)).astype(np.float32)
+    alphas[:5] = 0.9  # boundary: not a hit (strict >)
+    origin, direction = (0.5, -1.0, 2.0), (0.0, 0.6, -0.8)
+    got = z_depth(torch.from_numpy(coords), torch.from_numpy(alphas), origin, direction, max_depth).numpy()
+    along = ((coords - np.array(origin, np.float32)) @ np.array(direction, np.float32))[:, None] / (alphas + 1e-8)
+    want = np.clip(np.where(alphas > 0.9, along, max_depth), 0.0, max_depth) / max_depth
+    assert got.shape == (n, 1) and np.abs(got - want).max() < 1e-6
+    assert (got[:5] == 1.0).all() and got.min() >= 0.0 and got.max() <= 1.0
+    # 16-bit quantisation used by the script: truncation of depth * 0xFFFF
+    q = (got.reshape(-1) * 0xFFFF).astype(np.uint32)
+    assert q.max() == 0xFFFF and q.dtype == np.uint32
+
+    center, radius = np.array([0.1, 0.2, -0.3]), 3.5
+    view = random_view(np.random.RandomState(4), center, radius)
+    z, x, y = (np.array(v) for v in (view.camera_direction, view.x_axis, view.y_axis))
+    assert abs(np.linalg.norm(z) - 1) < 1e-12 and abs(np.linalg.norm(x) - 1) < 1e-12 and x[2] == 0.0
+    assert abs(z @ x) < 1e-12 and np.abs(np.cross(z, x) - y).max() < 1e-12
+    assert np.abs(np.array(view.camera_origin) - (center - z * radius)).max() < 1e-12  # looks at the centre
+    assert view.x_fov == view.y_fov == 60.0 * np.pi / 180

@@ -6,6 +6,7 @@ PSNR = -10 log10(mean(((out - target)/2)^2)) with out, target in [-1, 1] (SURVEY
 """
 import os
 import re
+import json
 import subprocess
 import sys
 
@@ -77,3 +78,35 @@ def test_train_resume_render(tmp_path, coarse, fine, batch, steps, min_psnr):
     p = psnr(img, ref)
     print(f"coarse={coarse} fine={fine}: PSNR {p:.2f} dB after {steps} steps, loss {first:.4f} -> {last:.4f}")
     assert p > min_psnr
+    if fine == 0:
+        return
+    # scripts/render_new_dataset.py: random poses -> NNNNN.json / NNNNN.png / NNNNN_depth.png (16-bit z-depth)
+    from learn_nerf.dataset import CameraView, FileNeRFView
+
+    out_dir = str(tmp_path / "new_views")
+    run([os.path.join(SCRIPTS, "render_new_dataset.py"), "--seed", "3", "--batch_size", "512", "--coarse_samples",
+         str(coarse), "--fine_samples", str(fine), "--num_images", "2", "--size", "24", "--distance", "1.5",
+         "--max_depth", "10", "--model_path", ckpt, os.path.join(data, "metadata.json"), out_dir])
+    assert sorted(os.listdir(out_dir)) == ["00000.json", "00000.png", "00000_depth.png", "00001.json", "00001.png",
+                                           "00001_depth.png", "metadata.json"]
+    meta = json.load(open(os.path.join(data, "metadata.json")))
+    radius = 1.5 * np.linalg.norm(np.array(meta["min"]) - np.array(meta["max"]))
+    half_diag = 0.5 * np.linalg.norm(np.array(meta["min"]) - np.array(meta["max"]))
+    for i in range(2):
+        view = CameraView.from_json(os.path.join(out_dir, f"{i:05}.json"))
+        assert abs(np.linalg.norm(view.camera_origin - (np.array(meta["min"]) + np.array(meta["max"])) / 2) - radius) < 1e-5
+        assert abs(np.dot(view.camera_direction, view.x_axis)) < 1e-6 and abs(view.x_fov - np.pi / 3) < 1e-12
+        color = np.array(Image.open(os.path.join(out_dir, f"{i:05}.png")))
+        depth_img = Image.open(os.path.join(out_dir, f"{i:05}_depth.png"))
+        depth = np.array(depth_img).astype(np.float64) / 0xFFFF * 10.0
+        assert color.shape == (24, 24, 3) and color.dtype == np.uint8 and depth.shape == (24, 24)
+        assert depth_img.mode in ("I;16", "I", "I;16B")
+        hit = depth < 9.99  # pixels that hit the cube with probability > 0.9
+        assert 0.02 < hit.mean() < 0.9, hit.mean()
+        # the surface lies inside the bounding box: z-depth within radius +- half the diagonal
+        assert depth[hit].min() > radius - half_diag - 0.05 and depth[hit].max() < radius + half_diag + 0.05
+        assert color[hit].mean() > color[~hit].mean()  # object brighter than the (black) background
+    # the colour views are readable as dataset views again (f1/f2 formats; like the reference, load_dataset
+    # itself would trip over the *_depth.png files, which have no camera json)
+    v0 = FileNeRFView.from_json(os.path.join(out_dir, "00000.json"), image_path=os.path.join(out_dir, "00000.png"))
+    assert v0.rays().shape == (24 * 24, 3, 3)
