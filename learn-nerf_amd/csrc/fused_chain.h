@@ -49,19 +49,18 @@ __device__ __forceinline__ bf16x8 zero_frag() { return bits_to_frag(make_uint4(0
 // T+2 is written from registers into the slot freed by stage T-1, stage T+4 is requested from L2.
 // Because stage T+1 is visible during stage T, the per-wave FIFO of A-fragments (kFragAhead LDS reads
 // in flight) runs continuously across stage boundaries.
-template <int NSTAGES, class SEQ, int WAVES = kWaves>
+template <int NSTAGES, class SEQ>
 struct Ring {
-  static constexpr int kPerWave = kStageFrags / WAVES;  // fragments of a stage moved by one wave
   const char* stream;  // global, NSTAGES * 16 KiB, fragment order
   int wave, lane;
-  uint4 r[2][kPerWave];
+  uint4 r[2][2];
   bf16x8 fifo[kFragAhead];
 
   template <int T>
   __device__ __forceinline__ void load() {
 #pragma unroll
-    for (int q = 0; q < kPerWave; ++q) {
-      const int f = wave + WAVES * q;
+    for (int q = 0; q < 2; ++q) {
+      const int f = wave + kWaves * q;
       r[T & 1][q] = *reinterpret_cast<const uint4*>(stream + ((int64_t)T * kStageFrags + f) * kFragBytes +
                                                     lane * 16);
     }
@@ -69,8 +68,8 @@ struct Ring {
   template <int T>
   __device__ __forceinline__ void write() {
 #pragma unroll
-    for (int q = 0; q < kPerWave; ++q) {
-      const int f = wave + WAVES * q;
+    for (int q = 0; q < 2; ++q) {
+      const int f = wave + kWaves * q;
       *reinterpret_cast<uint4*>(&smem[(T % kSlots) * kStageBytes + f * kFragBytes + lane * 16]) = r[T & 1][q];
     }
   }
@@ -204,29 +203,6 @@ __device__ __forceinline__ void chain_layer(RING& ring, Init init, GetB getb, Ep
       __builtin_amdgcn_sched_barrier(0);
     });
     epi(o_, acc);
-  });
-}
-
-// Two evaluation tiles per wave: every A-fragment read from LDS feeds two MFMAs.  (With one tile per wave
-// the 8 waves of a CU need 4 KiB of A-fragments per 32-cycle MFMA slot = the LDS peak of 128 B/clk, which
-// caps the MFMA pipe at the LDS read efficiency.)
-template <int C0, int NK, int NO, class RING, class Init, class GetB, class Epi>
-__device__ __forceinline__ void chain_layer2(RING& ring, Init init, GetB getb, Epi epi) {
-  std::integral_constant<int, 0> t0;
-  std::integral_constant<int, 1> t1;
-  static_for<NO>([&](auto o_) {
-    constexpr int o = decltype(o_)::value;
-    f32x16 acc0 = init(o_);
-    f32x16 acc1 = acc0;
-    static_for<NK>([&](auto k_) {
-      constexpr int ks = decltype(k_)::value;
-      const bf16x8 a = ring.template next<C0 + o * NK + ks>();
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, getb(k_, t0), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, getb(k_, t1), acc1, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    epi(o_, acc0, t0);
-    epi(o_, acc1, t1);
   });
 }
 

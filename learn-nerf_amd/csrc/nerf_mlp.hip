@@ -204,213 +204,6 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward, two evaluation tiles per wave: workgroup = 4 waves (one per SIMD, up to 512 unified registers
-// each) x 64 evaluations.  Same weight stream, bias block and dump layout as nerf_fwd_kernel.
-// ---------------------------------------------------------------------------------------------
-constexpr int kWaves2 = 4;
-constexpr int kThreads2 = kWaves2 * 64;
-constexpr int kTpw = 2;  // tiles per wave
-
-template <bool SAVE, bool FROM_RAYS>
-__global__ __launch_bounds__(kThreads2) __attribute__((amdgpu_waves_per_eu(1, 1))) void nerf_fwd2_kernel(
-    const char* __restrict__ packed, const float* __restrict__ xin_g, const float* __restrict__ din_g,
-    const float* __restrict__ rays, int64_t ray_stride, const float* __restrict__ ts, int T, int64_t M,
-    int64_t n_tiles, float* __restrict__ density, float* __restrict__ rgb, char* __restrict__ save) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
-  const int64_t tile0 = ((int64_t)blockIdx.x * kWaves2 + wave) * kTpw;
-
-  {
-    const float* bias_g = reinterpret_cast<const float*>(packed + kPackBiasOff);
-    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
-    for (int i = tid; i < kBiasFloats; i += kThreads2) bias_l[i] = bias_g[i];
-  }
-  float px[kTpw][3], pd[kTpw][3];
-  bool valid[kTpw], tile_ok[kTpw];
-  int64_t mm[kTpw];
-  static_for<kTpw>([&](auto t_) {
-    constexpr int t = decltype(t_)::value;
-    const int64_t tile = tile0 + t;
-    const int64_t m = tile * kTileCols + c;
-    mm[t] = m;
-    valid[t] = m < M;
-    tile_ok[t] = tile < n_tiles;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) px[t][a] = pd[t][a] = 0.0f;
-    if (valid[t]) {
-      if (FROM_RAYS) {
-        const int64_t n = m / T;
-        const float tt = ts[m];
-        const float* r = rays + n * ray_stride;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          pd[t][a] = r[3 + a];
-          px[t][a] = r[a] + pd[t][a] * tt;  // render.py:153
-        }
-      } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          px[t][a] = xin_g[m * 3 + a];
-          pd[t][a] = din_g[m * 3 + a];
-        }
-      }
-    }
-  });
-  __syncthreads();
-
-  Ring<kFwdStages, FwdSeq, kWaves2> ring;
-  ring.stream = packed + kPackFwdOff;
-  ring.wave = wave;
-  ring.lane = lane;
-  ring.prologue();
-
-  bf16x8 xe[kTpw][4], de[kTpw][2];
-  static_for<kTpw>([&](auto t_) {
-    constexpr int t = decltype(t_)::value;
-    static_for<4>([&](auto ks_) {
-      constexpr int ks = decltype(ks_)::value;
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        const int p = 4 * ks + pp;
-        float s = 0.0f, co = 0.0f;
-        if (p < 15) {
-          const int pg = 15 * h + p;
-          const int cd = pg / 10, f = pg - 10 * cd;
-          const float v = cd == 0 ? px[t][0] : (cd == 1 ? px[t][1] : px[t][2]);
-          sincos_pe(v * (float)(1 << f), &s, &co);
-        }
-        xe[t][ks][2 * pp] = (__bf16)s;
-        xe[t][ks][2 * pp + 1] = (__bf16)co;
-      }
-    });
-    static_for<2>([&](auto ks_) {
-      constexpr int ks = decltype(ks_)::value;
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        const int p = 4 * ks + pp;
-        float s = 0.0f, co = 0.0f;
-        if (p < 6) {
-          const int pg = 6 * h + p;
-          const int cd = pg >> 2, f = pg & 3;
-          const float v = cd == 0 ? pd[t][0] : (cd == 1 ? pd[t][1] : pd[t][2]);
-          sincos_pe(v * (float)(1 << f), &s, &co);
-        }
-        de[t][ks][2 * pp] = (__bf16)s;
-        de[t][ks][2 * pp + 1] = (__bf16)co;
-      }
-    });
-  });
-
-  DumpAddr dump[kTpw] = {{save, n_tiles, tile0, c, h}, {save, n_tiles, tile0 + 1, c, h}};
-  auto save_frag = [&](auto t_, int slot, const bf16x8& f) {
-    constexpr int t = decltype(t_)::value;
-    if (SAVE && tile_ok[t]) stream_store(dump[t].at(slot), frag_to_bits(f));
-  };
-  if (SAVE) {
-    static_for<kTpw>([&](auto t_) {
-      constexpr int t = decltype(t_)::value;
-      static_for<4>([&](auto i) { save_frag(t_, kSaveXin + decltype(i)::value, xe[t][decltype(i)::value]); });
-      static_for<2>([&](auto i) { save_frag(t_, kSaveDin + decltype(i)::value, de[t][decltype(i)::value]); });
-    });
-  }
-
-  bf16x8 a0[kTpw][16], a1[kTpw][16];
-  unsigned mask_bits[kTpw][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-
-  auto hidden = [&](auto s_, bf16x8(&in)[kTpw][16], bf16x8(&out)[kTpw][16], auto relu_, int save_slot) {
-    constexpr int S = decltype(s_)::value;
-    constexpr bool RELU = decltype(relu_)::value;
-    chain_layer2<fwd_cons_base(S), fwd_nk(S), fwd_no(S)>(
-        ring, [&](auto o_) { return bias_acc(fwd_bias_base(S) + 32 * decltype(o_)::value, h); },
-        [&](auto k_, auto t_) -> bf16x8 {
-          constexpr int ks = decltype(k_)::value;
-          constexpr int t = decltype(t_)::value;
-          if constexpr (S == 0) return xe[t][ks];
-          else if constexpr (ks < 16) return in[t][ks];
-          else return xe[t][ks - 16];
-        },
-        [&](auto o_, const f32x16& acc, auto t_) {
-          constexpr int o = decltype(o_)::value;
-          constexpr int t = decltype(t_)::value;
-#ifdef LNRF_EXP_NOEPI
-          out[t][2 * o] = bits_to_frag(make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])));
-          out[t][2 * o + 1] = bits_to_frag(make_uint4(__float_as_uint(acc[8]), __float_as_uint(acc[9]), __float_as_uint(acc[10]), __float_as_uint(acc[11])));
-#else
-          out[t][2 * o] = acc_to_frag<0, RELU>(acc);
-          out[t][2 * o + 1] = acc_to_frag<1, RELU>(acc);
-#endif
-          save_frag(t_, save_slot + 2 * o, out[t][2 * o]);
-          save_frag(t_, save_slot + 2 * o + 1, out[t][2 * o + 1]);
-          if constexpr (SAVE && RELU)
-            mask_bits[t][o >> 1] |= relu_bits(out[t][2 * o], out[t][2 * o + 1]) << (16 * (o & 1));
-        });
-    if constexpr (SAVE && RELU) {
-      static_for<kTpw>([&](auto t_) {
-        constexpr int t = decltype(t_)::value;
-        if (tile_ok[t])
-          *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile0 + t) * kFragBytes + lane * 16) =
-              make_uint4(mask_bits[t][0], mask_bits[t][1], mask_bits[t][2], mask_bits[t][3]);
-        mask_bits[t][0] = mask_bits[t][1] = mask_bits[t][2] = mask_bits[t][3] = 0u;
-      });
-    }
-  };
-  std::true_type relu;
-  std::false_type lin;
-  hidden(std::integral_constant<int, 0>{}, a1, a0, relu, kSaveH + 0 * 16);
-  hidden(std::integral_constant<int, 1>{}, a0, a1, relu, kSaveH + 1 * 16);
-  hidden(std::integral_constant<int, 2>{}, a1, a0, relu, kSaveH + 2 * 16);
-  hidden(std::integral_constant<int, 3>{}, a0, a1, relu, kSaveH + 3 * 16);
-  hidden(std::integral_constant<int, 4>{}, a1, a0, relu, kSaveH + 4 * 16);
-  hidden(std::integral_constant<int, 5>{}, a0, a1, relu, kSaveH + 5 * 16);
-  hidden(std::integral_constant<int, 6>{}, a1, a0, relu, kSaveH + 6 * 16);
-  hidden(std::integral_constant<int, 7>{}, a0, a1, relu, kSaveH + 7 * 16);
-  hidden(std::integral_constant<int, 8>{}, a1, a0, lin, kSaveZ);
-
-  chain_layer2<fwd_cons_base(9), fwd_nk(9), fwd_no(9)>(
-      ring, [&](auto o_) { return bias_acc(fwd_bias_base(9) + 32 * decltype(o_)::value, h); },
-      [&](auto k_, auto t_) -> bf16x8 {
-        constexpr int ks = decltype(k_)::value;
-        constexpr int t = decltype(t_)::value;
-        if constexpr (ks < 16) return a0[t][ks];
-        else return de[t][ks - 16];
-      },
-      [&](auto o_, const f32x16& acc, auto t_) {
-        constexpr int o = decltype(o_)::value;
-        constexpr int t = decltype(t_)::value;
-        if constexpr (o < 4) {
-          a1[t][2 * o] = acc_to_frag<0, true>(acc);
-          a1[t][2 * o + 1] = acc_to_frag<1, true>(acc);
-          save_frag(t_, kSaveH10 + 2 * o, a1[t][2 * o]);
-          save_frag(t_, kSaveH10 + 2 * o + 1, a1[t][2 * o + 1]);
-          if constexpr (SAVE) mask_bits[t][o >> 1] |= relu_bits(a1[t][2 * o], a1[t][2 * o + 1]) << (16 * (o & 1));
-        } else {
-          if constexpr (SAVE) {
-            if (tile_ok[t])
-              *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + 8) * n_tiles + tile0 + t) * kFragBytes +
-                                        lane * 16) = make_uint4(mask_bits[t][0], mask_bits[t][1], 0u, 0u);
-          }
-          if (h == 0 && valid[t]) {
-            const float x = acc[0];
-            density[mm[t]] = fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));  // softplus (model.py:57)
-          }
-        }
-      });
-  chain_layer2<fwd_cons_base(10), fwd_nk(10), fwd_no(10)>(
-      ring, [&](auto) { return bias_acc(fwd_bias_base(10), h); },
-      [&](auto k_, auto t_) -> bf16x8 { return a1[decltype(t_)::value][decltype(k_)::value]; },
-      [&](auto, const f32x16& acc, auto t_) {
-        constexpr int t = decltype(t_)::value;
-        if (h == 0 && valid[t]) {
-          rgb[mm[t] * 3 + 0] = tanhf(acc[0]);
-          rgb[mm[t] * 3 + 1] = tanhf(acc[1]);
-          rgb[mm[t] * 3 + 2] = tanhf(acc[2]);
-        }
-      });
-}
-
-// ---------------------------------------------------------------------------------------------
 // Backward, part 1: input-gradient chain.  Produces dy_l (pre-activation gradients) dumps.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBwdStages = kBwdFrags / kStageFrags;  // 70
@@ -719,28 +512,12 @@ extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packe
     hipLaunchKernelGGL((nerf_fwd_kernel<SAVE, RAYS>), grid, block, kFusedLds, st, (const char*)packed, \
                        x, d, rays, ray_stride, ts, (int)t, m, n_tiles, density, rgb, (char*)save);   \
   } while (0)
-  static const int tpw = getenv("LNRF_FWD_TPW") ? atoi(getenv("LNRF_FWD_TPW")) : 1;
-  const dim3 grid2((unsigned)((n_tiles + kWaves2 * kTpw - 1) / (kWaves2 * kTpw))), block2(kThreads2);
-#define LAUNCH_FWD2(SAVE, RAYS)                                                                         \
-  do {                                                                                                  \
-    rc = ensure_lds(nerf_fwd2_kernel<SAVE, RAYS>, kFusedLds);                                           \
-    if (rc) return rc;                                                                                  \
-    hipLaunchKernelGGL((nerf_fwd2_kernel<SAVE, RAYS>), grid2, block2, kFusedLds, st, (const char*)packed, \
-                       x, d, rays, ray_stride, ts, (int)t, m, n_tiles, density, rgb, (char*)save);      \
-  } while (0)
-  if (tpw == 2) {
-    if (save) {
-      if (from_rays) LAUNCH_FWD2(true, true); else LAUNCH_FWD2(true, false);
-    } else {
-      if (from_rays) LAUNCH_FWD2(false, true); else LAUNCH_FWD2(false, false);
-    }
-  } else if (save) {
+  if (save) {
     if (from_rays) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false);
   } else {
     if (from_rays) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false);
   }
 #undef LAUNCH_FWD
-#undef LAUNCH_FWD2
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
