@@ -264,9 +264,9 @@ __global__ void hashgrid_bwd_sliced_kernel(HashGridDesc d, LevelList ll, const f
 // counts its chunk per slice in LDS, reserves room in each slice's global bucket with ONE atomic per
 // (workgroup, slice), writes its tuples there and records the level's max |value|.
 // Pass B gives every (level, slice) bucket to one workgroup (few-slice levels: several), which converts the
-// values to fixed point with the power-of-two scale that maps the level's max to 2^44 (exact products, 2^19
-// terms of headroom, resolution 2^-44 of the max), accumulates them with ds_add_u64 and adds the slice to
-// the gradient table.  Integer accumulation is order-independent, so unsplit slices are bit-reproducible.
+// values to fixed point with the power-of-two scale 2^(62 - lg - e) (level max < 2^e, fewer than 2^lg tuples
+// in the bucket: the sum cannot overflow; resolution 2^-46 of the max for a 64K-tuple bucket), accumulates
+// them with ds_add_u64 and adds the slice to the gradient table.  Integer accumulation is order-independent, so unsplit slices are bit-reproducible.
 // Buckets are sized 1.25x the mean for hashed levels (the hash spreads samples evenly), 4x for dense levels;
 // overflowing tuples fall back to global atomics.
 struct BucketTuple {
@@ -276,7 +276,6 @@ struct BucketTuple {
 constexpr int kBinChunk = 2048;  // samples per binning workgroup
 constexpr int kBucketEntries = 4096;  // 64 KiB of int64 x 2 features
 constexpr int kMaxSlices = 256;       // table <= 1M entries
-constexpr int kFixedBits = 44;
 
 struct BucketPlan {
   int n;                 // bucketed levels
@@ -411,13 +410,16 @@ __global__ __launch_bounds__(kReduceThreads) void hashgrid_reduce_kernel(
   const int T = d.table_size[level];
   for (int i = threadIdx.x; i < kBucketEntries * 2; i += kReduceThreads) lds_q[i] = 0ull;
   __syncthreads();
-  // power-of-two scale: level max < 2^e  ->  values < 2^kFixedBits
-  int e = 0;
-  frexpf(__uint_as_float(level_max[li]), &e);
-  const double scale = ldexp(1.0, kFixedBits - e), inv_scale = ldexp(1.0, e - kFixedBits);
   long long count = cursors[plan.cursor_off[li] + b];
   if (count > plan.cap[li]) count = plan.cap[li];
   const long long lo = count * part / split, hi = count * (part + 1) / split;
+  // power-of-two scale: level max < 2^e and at most n = hi - lo < 2^lg terms per entry, so values scaled by
+  // 2^(62 - lg - e) cannot overflow the signed 64-bit sum whatever the sample distribution is
+  int e = 0;
+  frexpf(__uint_as_float(level_max[li]), &e);
+  const int lg = 64 - __clzll((hi - lo) | 1ll);
+  const int fixed_bits = 62 - lg;  // 46 for a 64K-tuple bucket
+  const double scale = ldexp(1.0, fixed_bits - e), inv_scale = ldexp(1.0, e - fixed_bits);
   const BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li] + (long long)b * plan.cap[li];
   for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += (long long)kReduceUnroll * kReduceThreads) {
     BucketTuple t[kReduceUnroll];
