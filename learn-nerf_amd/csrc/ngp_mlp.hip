@@ -314,7 +314,7 @@ struct NgpWgradEpi {
     return r16 < nv ? base + r16 : -1;
   }
 };
-constexpr int kNgpWgSpi = 6;  // steps per barrier
+constexpr int kNgpWgSpi = 4;  // steps per barrier: 2 x 4 x 8 KiB = 64 KiB of LDS, two workgroups per CU
 constexpr int kNgpWgradLds = 2 * kNgpWgSpi * 8 * kFragBytes;
 
 __global__ __launch_bounds__(kThreads) void ngp_wgrad_kernel(NgpWgradArgs args, const char* __restrict__ scratch,
@@ -505,7 +505,7 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
     p.b_lo = (unsigned)(off.b[layer] & 0xFFFFFFFFll); p.b_hi = (unsigned)(off.b[layer] >> 32);
     p.rb0 = rb0; p.rv0 = rv0; p.rb1 = rb1; p.rv1 = rv1;
     p.rb2 = rb2; p.rv2 = rv2; p.rb3 = rb3; p.rv3 = rv3;
-    int64_t nb = 64;
+    int64_t nb = 102;  // 5 problems x 102 = 510 workgroups = two per CU
     const int64_t max_nb = (n_tiles + 2 * kNgpWgSpi - 1) / (2 * kNgpWgSpi);
     if (nb > max_nb) nb = max_nb;
     p.first_block = first;

@@ -242,3 +242,36 @@ def test_z_depth_and_random_view_match_reference_formulas():
     assert abs(z @ x) < 1e-12 and np.abs(np.cross(z, x) - y).max() < 1e-12
     assert np.abs(np.array(view.camera_origin) - (center - z * radius)).max() < 1e-12  # looks at the centre
     assert view.x_fov == view.y_fov == 60.0 * np.pi / 180
+
+
+def test_pan_and_spin_camera_paths():
+    """scripts/render_nerf_pan.py:22-52 and render_nerf_spin.py:22-33 restated with explicit formulas."""
+    import math
+
+    import numpy as np
+
+    from learn_nerf.dataset import CameraView
+    from learn_nerf.scripts.camera_paths import pan_views, spin_views
+
+    lo, hi = (-1.0, -2.0, 0.0), (1.0, 2.0, 1.0)
+    views = list(pan_views(lo, hi, 8, 2.0))
+    center, diag = (np.array(lo) + np.array(hi)) / 2, np.linalg.norm(np.array(lo) - np.array(hi))
+    assert len(views) == 8
+    for i, v in enumerate(views):
+        th = 2 * math.pi * i / 8
+        z = np.array([math.cos(th), -math.sin(th), 0.0])  # e1 = x, e2 = (0,0,-1) x (1,0,0) = (0,-1,0)
+        assert np.abs(np.array(v.camera_direction) - z).max() < 1e-12
+        assert np.abs(np.array(v.camera_origin) - (center - z * diag * 2.0)).max() < 1e-12
+        assert v.y_axis == (0.0, 0.0, -1.0) and abs(np.dot(v.x_axis, v.camera_direction)) < 1e-12
+        assert v.x_fov == v.y_fov == math.pi / 3
+    custom = list(pan_views(lo, hi, 4, 1.0, axis=(0.0, 3.0, 4.0)))
+    assert np.abs(np.array(custom[0].y_axis) - np.array([0.0, 0.6, 0.8])).max() < 1e-12
+    assert np.abs(np.array(custom[0].camera_direction) - np.array([-1.0, 0.0, 0.0])).max() < 1e-12
+    base = CameraView(camera_direction=(0.0, 0.0, 1.0), camera_origin=(1.0, 2.0, 3.0), x_axis=(1.0, 0.0, 0.0),
+                      y_axis=(0.0, 1.0, 0.0), x_fov=0.5, y_fov=0.4)
+    spun = list(spin_views(base, 4))
+    assert spun[0].x_axis == (1.0, 0.0, 0.0) and spun[0].camera_direction == (0.0, 0.0, 1.0)
+    assert np.abs(np.array(spun[1].x_axis) - np.array([0.0, 0.0, 1.0])).max() < 1e-12      # quarter turn: x -> z
+    assert np.abs(np.array(spun[1].camera_direction) - np.array([-1.0, 0.0, 0.0])).max() < 1e-12
+    assert all(v.camera_origin == base.camera_origin and v.y_axis == base.y_axis and v.x_fov == 0.5 for v in spun)
+    assert base.x_axis == (1.0, 0.0, 0.0)  # the input view is not modified

@@ -80,6 +80,20 @@ def test_train_resume_render(tmp_path, coarse, fine, batch, steps, min_psnr):
     assert p > min_psnr
     if fine == 0:
         return
+    # scripts/render_nerf_pan.py / render_nerf_spin.py: camera paths around / about the scene, frames side by side
+    small = ["--seed", "0", "--batch_size", "512", "--coarse_samples", str(coarse), "--fine_samples", str(fine),
+             "--width", "16", "--height", "16", "--model_path", ckpt]
+    pan_png, spin_png = str(tmp_path / "pan.png"), str(tmp_path / "spin.png")
+    run([os.path.join(SCRIPTS, "render_nerf_pan.py")] + small + ["--frames", "3", "--distance", "1.5",
+                                                                  os.path.join(data, "metadata.json"), pan_png])
+    run([os.path.join(SCRIPTS, "render_nerf_spin.py")] + small + ["--frames", "2", os.path.join(data, "metadata.json"),
+                                                                   os.path.join(data, "0000.json"), spin_png])
+    pan = np.array(Image.open(pan_png).convert("RGB"))
+    spin = np.array(Image.open(spin_png).convert("RGB"))
+    assert pan.shape == (16, 48, 3) and spin.shape == (16, 32, 3)
+    assert pan.max() > 40  # the object is visible from the orbit
+    # spin frame 0 is the unrotated view 0000 at 16x16; frame 1 looks the opposite way (background only)
+    assert spin[:, :16].max() > 40 and spin[:, 16:].max() < 30
     # scripts/render_new_dataset.py: random poses -> NNNNN.json / NNNNN.png / NNNNN_depth.png (16-bit z-depth)
     from learn_nerf.dataset import CameraView, FileNeRFView
 
