@@ -333,7 +333,13 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const unsigned idx = entry_index(k.base[0] + (c >> 2), k.base[1] + ((c >> 1) & 1), k.base[2] + (c & 1), G, T, hashed);
-      run_reserve(s_count, idx / kBucketEntries, valid);
+      // hashed levels spread a wave over many slices (little same-address contention): plain LDS atomics are
+      // cheaper than the run detection; dense levels put whole runs of lanes into one slice
+      if (hashed) {
+        if (valid) atomicAdd(&s_count[idx / kBucketEntries], 1u);
+      } else {
+        run_reserve(s_count, idx / kBucketEntries, valid);
+      }
     }
   }
   __syncthreads();
@@ -366,7 +372,7 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
       }
       const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
       const unsigned b = idx / kBucketEntries;
-      const unsigned off = run_reserve(s_count, b, valid);
+      const unsigned off = hashed ? (valid ? atomicAdd(&s_count[b], 1u) : 0u) : run_reserve(s_count, b, valid);
       if (valid) {
         const long long pos = (long long)s_base[b] + off;
         vmax = fmaxf(vmax, fmaxf(fabsf(w * g0), fabsf(w * g1)));
