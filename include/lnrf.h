@@ -133,6 +133,17 @@ int lnrf_composite_bwd(const float* ts, const float* t_min, const float* t_max,
 int lnrf_sinusoidal_emb(const float* x, int64_t ldx, int64_t m, int32_t dims, int32_t freqs,
                         float* out, int64_t ldo, int64_t col_off, lnrf_stream_t stream);
 
+/* Operand precision of the generic dense path (lnrf_dense_fwd / _bwd_input / _bwd_weight / lnrf_gemm_f32), a
+ * thread-local mode like a rounding mode.  LNRF_DENSE_FP32 (default): exact fp32 products on the f32 MFMA, the
+ * arithmetic of the reference's jnp.float32 Dense layers.  LNRF_DENSE_BF16: both operands of every product are
+ * rounded to bf16 (round-to-nearest-even) when staged, fp32 accumulate / bias / activation — the arithmetic of the
+ * fused kernels, for the models that have no fused kernel (RefNERFModel, InstantNGPRefNERFModel, non-default
+ * shapes). */
+#define LNRF_DENSE_FP32 0
+#define LNRF_DENSE_BF16 1
+int lnrf_set_dense_precision(int32_t precision);
+int32_t lnrf_get_dense_precision(void);
+
 /* flax.linen.Dense + activation (model.py:51-60): y = act(x[M,K] @ w[K,N] + b[N]).
  * fp32 in / fp32 accumulate on the f32 MFMA.  ldx/ldy row strides (concat without copies).
  * b may be NULL. */

@@ -7,6 +7,10 @@
 namespace lnrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// operand precision of the dense path (lnrf_set_dense_precision): thread-local like lnrf_last_error
+static thread_local int g_dense_bf16 = 0;
 
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
@@ -36,6 +40,11 @@ constexpr int TI = 64, TJ = 64, RC = 16;
 // C[i][j] (op)= sum_r A(i,r) * B(r,j),  A(i,r) = a[i*sa_i + r*sa_r],  B(r,j) = b[r*sb_r + j*sb_j].
 // One workgroup = 64x64 output tile, 4 waves in a 2x2 grid of 32x32 MFMA tiles.
 // mode 0: store act(C + bias);  1: C += result (plain);  2: atomicAdd (split reduction).
+// BF16 = false: exact fp32 products (v_mfma_f32_32x32x2_f32).  BF16 = true: operands rounded to bf16 while they
+// are staged into LDS, one v_mfma_f32_32x32x16_bf16 per 16-deep chunk, fp32 accumulate / bias / activation:
+// the arithmetic of the fused kernels for models that have no fused kernel (16x the MFMA rate; the kernel is
+// then bound by operand staging and by the fp32 activations in HBM).
+template <bool BF16>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, int64_t sa_i,
                                                        int64_t sa_r, const float* __restrict__ b,
                                                        int64_t sb_r, int64_t sb_j,
@@ -43,8 +52,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, int act,
                                                        int mode, int64_t I, int J, int64_t R,
                                                        int64_t r_per_split) {
-  __shared__ float As[TI][RC + 1];
-  __shared__ float Bs[RC][TJ + 4];
+  // fp32: As[i][r], Bs[r][j].  bf16: both operands r-contiguous (8 k-values per lane = one 16-byte read)
+  __shared__ float As[BF16 ? 1 : TI][RC + 1];
+  __shared__ float Bs[BF16 ? 1 : RC][TJ + 4];
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[BF16 ? TI : 1][RC + 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[BF16 ? TJ : 1][RC + 8];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -89,14 +101,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
       const int e = q * 256 + tid;
       int ii, rr;
       if (a_r_fast) { rr = e % RC; ii = e / RC; } else { ii = e % TI; rr = e / TI; }
-      As[ii][rr] = ra[q];
+      if constexpr (BF16) Ah[ii][rr] = (__bf16)ra[q];
+      else As[ii][rr] = ra[q];
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int e = q * 256 + tid;
       int jj, rr;
       if (b_j_fast) { jj = e % TJ; rr = e / TJ; } else { rr = e % RC; jj = e / RC; }
-      Bs[rr][jj] = rb[q];
+      if constexpr (BF16) Bh[jj][rr] = (__bf16)rb[q];
+      else Bs[rr][jj] = rb[q];
     }
   };
   if (r_begin < r_end) fetch(r_begin);
@@ -104,11 +118,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     stage();
     __syncthreads();
     if (r0 + RC < r_end) fetch(r0 + RC);
+    if constexpr (BF16) {
+      static_assert(RC == 16, "one 32x32x16 MFMA per chunk");
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Ah[wr * 32 + (lane & 31)][8 * (lane >> 5)]);
+      const bf16x8 bv = *reinterpret_cast<const bf16x8*>(&Bh[wc * 32 + (lane & 31)][8 * (lane >> 5)]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < RC / 2; ++kk) {
-      const float av = As[wr * 32 + (lane & 31)][kk * 2 + (lane >> 5)];
-      const float bv = Bs[kk * 2 + (lane >> 5)][wc * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int kk = 0; kk < RC / 2; ++kk) {
+        const float av = As[wr * 32 + (lane & 31)][kk * 2 + (lane >> 5)];
+        const float bv = Bs[kk * 2 + (lane >> 5)][wc * 32 + (lane & 31)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -187,12 +208,23 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
   splits = (int)((R + per - 1) / per);
   if (splits < 1) splits = 1;
   dim3 grid((unsigned)((I + TI - 1) / TI), (unsigned)((J + TJ - 1) / TJ), (unsigned)splits);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, a, sa_i, sa_r, b, sb_r, sb_j, c, ldc,
-                     bias, act, mode, I, J, R, per);
+  if (g_dense_bf16)
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, a, sa_i, sa_r, b, sb_r, sb_j, c, ldc,
+                       bias, act, mode, I, J, R, per);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, stream, a, sa_i, sa_r, b, sb_r, sb_j, c, ldc,
+                       bias, act, mode, I, J, R, per);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "gemm_f32");
   return LNRF_OK;
 }
+
+extern "C" int lnrf_set_dense_precision(int32_t precision) {
+  LNRF_CHECK_ARG(precision == LNRF_DENSE_FP32 || precision == LNRF_DENSE_BF16, "precision must be LNRF_DENSE_FP32 or LNRF_DENSE_BF16");
+  g_dense_bf16 = precision == LNRF_DENSE_BF16;
+  return LNRF_OK;
+}
+extern "C" int32_t lnrf_get_dense_precision(void) { return g_dense_bf16 ? LNRF_DENSE_BF16 : LNRF_DENSE_FP32; }
 
 extern "C" int lnrf_dense_fwd(const float* x, int64_t ldx, const float* w, const float* b,
                               int32_t act, float* y, int64_t ldy, int64_t m, int32_t k, int32_t n,

@@ -224,6 +224,7 @@ class InstantNGPModel(ModelBase):
             out.append((k, b))
         return flat[:nt], out
 
+    @ops.uses_model_precision
     def forward_points(self, flat, x, d, save: bool):
         if self._use_fused():
             return self._fused_forward_points(flat, x, d, save)
@@ -265,6 +266,7 @@ class InstantNGPModel(ModelBase):
             ctx = dict(flat=flat, x=x, enc_t=enc_t, acts=acts, cat=cat, cacts=cacts, density=density, rgb=rgb, e0=e0)
         return density.view(-1), rgb, {}, ctx
 
+    @ops.uses_model_precision
     def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
         if ctx.get("kind") == "fused":
             return self._fused_backward(ctx, g_density, g_rgb, grad_flat)
@@ -330,6 +332,7 @@ class InstantNGPRefNERFModel(ModelBase):
     density_dim: int = 16
     density_layers: int = 1
     color_layers: int = 2
+    precision: str = "bf16"  # operands of the Dense layers: "bf16" (MFMA rate) | "fp32" (exact, parity gate)
     tag: str = "ngpref"
 
     def encoding(self) -> MultiresHashTableEncoding:
@@ -353,6 +356,7 @@ class InstantNGPRefNERFModel(ModelBase):
     init_flat_ = InstantNGPModel.init_flat_
     _dense_views = InstantNGPModel._dense_views
 
+    @ops.uses_model_precision
     def forward_points(self, flat, x, d, save: bool):
         if self.density_layers != 1:
             raise NotImplementedError("InstantNGPRefNERFModel: density_layers != 1")
@@ -390,6 +394,7 @@ class InstantNGPRefNERFModel(ModelBase):
                        nraw=nraw, density=density, diffuse=diffuse, spectral=spectral, cacts=cacts, dir_out=dir_out)
         return density, rgb, aux, ctx
 
+    @ops.uses_model_precision
     def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
         enc = self.encoding()
         desc = enc.desc()

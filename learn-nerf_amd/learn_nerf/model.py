@@ -232,6 +232,7 @@ class NeRFModel(ModelBase):
         self._dense_bwd(ctx, g_density, g_rgb, grad_flat)
 
     # ---- exact fp32 dense path (any shape) ------------------------------------------------------
+    @ops.uses_model_precision
     def _dense_fwd(self, flat, x, d, save: bool):
         tree = self.tree(flat)
         W = [(tree[f"Dense_{i}"]["kernel"], tree[f"Dense_{i}"]["bias"]) for i in range(len(self.layer_dims()))]
@@ -268,6 +269,7 @@ class NeRFModel(ModelBase):
                        density=density, rgb=rgb)
         return density.view(-1), rgb, {}, ctx
 
+    @ops.uses_model_precision
     def _dense_bwd(self, ctx, g_density, g_rgb, grad_flat):
         tree, gtree = self.tree(ctx["flat"]), self.tree(grad_flat)
         nl = len(self.layer_dims())

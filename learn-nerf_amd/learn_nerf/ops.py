@@ -3,6 +3,8 @@ Tensor-level wrappers over the C ABI (include/lnrf.h).  Each function allocates 
 with torch (device memory plumbing only) and enqueues one HIP kernel family on the current
 stream.  No arithmetic happens in Python.
 """
+import contextlib
+import functools
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -151,6 +153,32 @@ def composite_bwd(ts, t_min, t_max, mask, density, rgb, background, g_background
 
 
 # ---------------------------------------------------------------- generic dense (exact fp32)
+
+_DENSE_PRECISIONS = {"fp32": 0, "bf16": 1}  # LNRF_DENSE_FP32 / LNRF_DENSE_BF16
+
+
+@contextlib.contextmanager
+def dense_precision(precision: str):
+    """Operand precision of the generic dense kernels inside the block (lnrf_set_dense_precision, thread-local)."""
+    if precision not in _DENSE_PRECISIONS:
+        raise ValueError(f"unknown precision {precision!r}")
+    lib = L.lib()
+    previous = lib.lnrf_get_dense_precision()
+    L.check(lib.lnrf_set_dense_precision(_DENSE_PRECISIONS[precision]), "set_dense_precision")
+    try:
+        yield
+    finally:
+        lib.lnrf_set_dense_precision(previous)
+
+
+def uses_model_precision(method):
+    """Run a model method with the dense kernels in the model's `precision` ("bf16" | "fp32")."""
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with dense_precision(getattr(self, "precision", "fp32")):
+            return method(self, *args, **kwargs)
+    return wrapped
+
 
 def _ld(t: torch.Tensor) -> int:
     assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D view"

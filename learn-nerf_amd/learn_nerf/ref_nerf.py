@@ -59,6 +59,7 @@ class RefNERFModel(RefNERFBase):
     color_layer_dim: int = 128
     x_freqs: int = 10
     d_freqs: int = 4  # unused, as in the reference
+    precision: str = "bf16"  # operands of the Dense layers: "bf16" (MFMA rate) | "fp32" (exact, parity gate)
     tag: str = "refnerf"
 
     def layer_dims(self) -> List[Tuple[int, int]]:
@@ -99,6 +100,7 @@ class RefNERFModel(RefNERFBase):
         return out
 
     # ---- forward ------------------------------------------------------------------------------------
+    @ops.uses_model_precision
     def forward_points(self, flat, x, d, save: bool):
         W = self._views(flat)
         m, dev, hd = x.shape[0], flat.device, self.hidden_dim
@@ -151,6 +153,7 @@ class RefNERFModel(RefNERFBase):
         return density, rgb, aux, ctx
 
     # ---- backward -------------------------------------------------------------------------------------
+    @ops.uses_model_precision
     def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
         W = self._views(ctx["flat"])
         G = self._views(grad_flat)

@@ -50,19 +50,19 @@ def create_model(args: argparse.Namespace, metadata: ModelMetadata) -> Tuple[Mod
     Adam(0.9, 0.99, eps 1e-15) for --instant_ngp; sh_degree 4 for --ref_nerf.
     """
     use_ref = bool(getattr(args, "ref_nerf", False))
+    precision = getattr(args, "precision", "bf16")
     if getattr(args, "instant_ngp", False):
         from learn_nerf.instant_ngp import InstantNGPModel, InstantNGPRefNERFModel
 
         factory = partial(InstantNGPRefNERFModel, sh_degree=4) if use_ref else InstantNGPModel
-        box = dict(bbox_min=tuple(metadata.bbox_min), bbox_max=tuple(metadata.bbox_max))
+        box = dict(bbox_min=tuple(metadata.bbox_min), bbox_max=tuple(metadata.bbox_max), precision=precision)
         pair = [factory(table_sizes=[2 ** 18] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], **box)
                 for levels in (6, 16)]
         return pair[0], pair[1], dict(adam_eps=1e-15, adam_b1=0.9, adam_b2=0.99)
     if use_ref:
         from learn_nerf.ref_nerf import RefNERFModel
 
-        return RefNERFModel(sh_degree=4), RefNERFModel(sh_degree=4), {}
-    precision = getattr(args, "precision", "bf16")
+        return RefNERFModel(sh_degree=4, precision=precision), RefNERFModel(sh_degree=4, precision=precision), {}
     return NeRFModel(precision=precision), NeRFModel(precision=precision), {}
 
 

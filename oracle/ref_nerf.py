@@ -115,8 +115,10 @@ def ref_nerf_base(spatial_block, directional_block, x: torch.Tensor, d: torch.Te
 
 
 def ref_nerf_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, sh_degree=4, input_layers=5, mid_layers=4,
-                   hidden_dim=256, color_layer_dim=128, x_freqs=10):
-    """RefNERFModel (ref_nerf.py:80-107) -> (density, rgb, aux dict)."""
+                   hidden_dim=256, color_layer_dim=128, x_freqs=10, operand_round=None):
+    """RefNERFModel (ref_nerf.py:80-107) -> (density, rgb, aux dict).  ``operand_round`` (e.g.
+    oracle.model.bf16_round) is applied to both operands of every Dense matmul (models LNRF_DENSE_BF16)."""
+    rnd = operand_round if operand_round is not None else (lambda t: t)
     dims = ref_nerf_layer_dims(input_layers, mid_layers, hidden_dim, color_layer_dim, x_freqs, sh_degree)
     layers = unflatten(flat, dims)
 
@@ -125,19 +127,19 @@ def ref_nerf_model(flat: torch.Tensor, x: torch.Tensor, d: torch.Tensor, sh_degr
         z = x_emb
         li = 0
         for _ in range(input_layers):
-            z = torch.relu(z @ layers[li][0] + layers[li][1])
+            z = torch.relu(rnd(z) @ rnd(layers[li][0]) + layers[li][1])
             li += 1
         z = torch.cat([z, x_emb], dim=-1)
         for i in range(mid_layers):
             if i > 0:
                 z = torch.relu(z)
-            z = z @ layers[li][0] + layers[li][1]
+            z = rnd(z) @ rnd(layers[li][0]) + layers[li][1]
             li += 1
         return z
 
     def directional_block(inp):  # ref_nerf.py:105-107
         li = input_layers + mid_layers
-        h = torch.relu(inp @ layers[li][0] + layers[li][1])
-        return h @ layers[li + 1][0] + layers[li + 1][1]
+        h = torch.relu(rnd(inp) @ rnd(layers[li][0]) + layers[li][1])
+        return rnd(h) @ rnd(layers[li + 1][0]) + layers[li + 1][1]
 
     return ref_nerf_base(spatial_block, directional_block, x, d, sh_degree)

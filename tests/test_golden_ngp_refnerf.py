@@ -73,7 +73,7 @@ def test_hip_ngp_reproduces_golden(precision):
 def test_hip_ref_nerf_reproduces_golden():
     from learn_nerf.ref_nerf import RefNERFModel
 
-    model = RefNERFModel(**REF)
+    model = RefNERFModel(precision="fp32", **REF)
     flat = T("ref_flat", torch.float32).cuda()
     x, d = T("ref_x", torch.float32).cuda(), T("d", torch.float32).cuda()
     dens, rgb, aux, ctx = model.forward_points(flat, x, d, save=True)

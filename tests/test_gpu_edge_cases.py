@@ -101,16 +101,24 @@ def test_non_default_nerf_shape_uses_dense_path():
     from learn_nerf.model import NeRFModel
     from oracle import model as OM
 
-    model = NeRFModel(hidden_dim=64, color_layer_dim=32, x_freqs=6, d_freqs=2, input_layers=3, mid_layers=2)
+    model = NeRFModel(hidden_dim=64, color_layer_dim=32, x_freqs=6, d_freqs=2, input_layers=3, mid_layers=2,
+                      precision="fp32")
     assert not model.fused_supported()
     params = model.init(dict(params=0))["params"]
     gen = torch.Generator().manual_seed(0)
     x = (torch.rand(100, 3, generator=gen) * 2 - 1).float()
     d = torch.randn(100, 3, generator=gen).float()
-    dens, rgb, _ = model.apply(dict(params=params), x.cuda(), d.cuda())  # precision="bf16" but not fusable
+    dens, rgb, _ = model.apply(dict(params=params), x.cuda(), d.cuda())  # exact dense path
     rd, rr, _ = OM.nerf_mlp(model.flat(params).cpu().double(), x.double(), d.double(), input_layers=3, mid_layers=2,
                             hidden_dim=64, color_layer_dim=32, x_freqs=6, d_freqs=2)
     assert (rgb.cpu().double() - rr).abs().max().item() < 2e-5
+    # precision="bf16" on a shape without a fused kernel: bf16 operands on the same dense path
+    model16 = NeRFModel(hidden_dim=64, color_layer_dim=32, x_freqs=6, d_freqs=2, input_layers=3, mid_layers=2)
+    _, rgb16, _ = model16.apply(dict(params=params), x.cuda(), d.cuda())
+    _, rr16, _ = OM.nerf_mlp(model.flat(params).cpu().float(), x, d, input_layers=3, mid_layers=2, hidden_dim=64,
+                             color_layer_dim=32, x_freqs=6, d_freqs=2, operand_round=OM.bf16_round)
+    assert (rgb16.cpu() - rr16).abs().max().item() < 2e-3
+    assert (rgb16.cpu().double() - rr).abs().max().item() > 1e-5
 
 
 def test_cpu_tensor_is_rejected_loudly():

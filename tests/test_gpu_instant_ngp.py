@@ -152,13 +152,21 @@ def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m):
 
 
 def test_ngp_fused_unsupported_shape_uses_dense_path():
+    """hidden_dim 32 has no fused kernel: precision="bf16" then means bf16 operands on the generic dense path."""
+    from oracle.model import bf16_round
+
     model, params, flat = make_model(4, 2 ** 10, hidden=32, precision="bf16")
     assert not model._use_fused()
     x, d, _ = points(100)
     dens, rgb, _ = model.apply(dict(params=params), x.cuda(), d.cuda())
-    rd, rr, _ = ON.ngp_model(flat.cpu().double(), x.double(), d.double(), model.table_sizes, model.grid_sizes, BMIN,
+    rd, rr, _ = ON.ngp_model(flat.cpu().float(), x, d, model.table_sizes, model.grid_sizes, BMIN, BMAX, hidden_dim=32,
+                             operand_round=bf16_round)
+    assert (rgb.cpu() - rr).abs().max().item() < 2e-3
+    model32, params32, flat32 = make_model(4, 2 ** 10, hidden=32, precision="fp32")
+    _, rgb32, _ = model32.apply(dict(params=params32), x.cuda(), d.cuda())
+    ed, er, _ = ON.ngp_model(flat32.cpu().double(), x.double(), d.double(), model.table_sizes, model.grid_sizes, BMIN,
                              BMAX, hidden_dim=32)
-    assert (rgb.cpu().double() - rr).abs().max().item() < 1e-4
+    assert (rgb32.cpu().double() - er).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -227,7 +235,7 @@ def test_ngp_ref_nerf_forward_backward(levels, table):
 
     grids = [2 ** (3 + i // 2) for i in range(levels)]
     model = InstantNGPRefNERFModel(sh_degree=4, table_sizes=[table] * levels, grid_sizes=grids, bbox_min=BMIN,
-                                   bbox_max=BMAX)
+                                   bbox_max=BMAX, precision="fp32")
     params = model.init(dict(params=5))["params"]
     flat = model.flat(params)
     nt = model.encoding().num_table_floats()

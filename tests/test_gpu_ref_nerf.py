@@ -34,10 +34,10 @@ def test_sh_and_ide_kernels(deg):
     assert (ide.cpu().double() - ORF.integrated_directional_encoding(deg, v.double(), r.double())).abs().max().item() < 2e-5
 
 
-def make_model(seed=3, **kw):
+def make_model(seed=3, precision="fp32", **kw):
     from learn_nerf.ref_nerf import RefNERFModel
 
-    model = RefNERFModel(**kw)
+    model = RefNERFModel(precision=precision, **kw)
     params = model.init(dict(params=seed))["params"]
     flat = model.flat(params)
     gen = torch.Generator().manual_seed(seed + 1)
@@ -99,7 +99,8 @@ def test_ref_nerf_train_step_matches_oracle():
 
     kw = dict(hidden_dim=64, color_layer_dim=32, sh_degree=4)
     n, tc, tf, lr = 96, 12, 20, 1e-3
-    loop = TrainLoop(RefNERFModel(**kw), RefNERFModel(**kw), init_rng=8, lr=lr, coarse_ts=tc, fine_ts=tf)
+    loop = TrainLoop(RefNERFModel(precision="fp32", **kw), RefNERFModel(precision="fp32", **kw), init_rng=8, lr=lr,
+                     coarse_ts=tc, fine_ts=tf)
     gen = torch.Generator().manual_seed(0)
     o = torch.randn(n, 3, generator=gen)
     o = 4 * o / o.norm(dim=-1, keepdim=True)
@@ -128,3 +129,66 @@ def test_ref_nerf_train_step_matches_oracle():
         tol = 2e-3 if k.endswith("normal_mse") else 1e-4
         assert abs(float(log[k]) - float(ld[k])) < tol * max(1.0, abs(float(ld[k]))), k
     assert rel < 5e-3
+
+
+@pytest.mark.parametrize("kw,m", [(dict(), 500), (dict(hidden_dim=64, color_layer_dim=32, sh_degree=3), 1500)])
+def test_ref_nerf_bf16_dense_path(kw, m):
+    """
+    precision="bf16": the generic dense kernels round both operands of every product to bf16
+    (LNRF_DENSE_BF16).  Gate: the oracle with the same operand rounding (autograd through the rounded products,
+    including the second-order normal term); tolerances as for the fused NeRFModel (rgb 4e-3, gradients 3e-2
+    relative L2).  The distance to the exact float64 model is printed.
+    """
+    from oracle.model import bf16_round
+
+    model, params, flat = make_model(precision="bf16", **kw)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(m, 3, generator=gen) * 2 - 1).float()
+    d = unit(m, seed=9)
+    okw = dict(sh_degree=model.sh_degree, hidden_dim=model.hidden_dim, color_layer_dim=model.color_layer_dim)
+    f32 = flat.cpu().float().requires_grad_(True)
+    rd, rr, raux = ORF.ref_nerf_model(f32, x, d, operand_round=bf16_round, **okw)
+    ed, er, eaux = ORF.ref_nerf_model(flat.cpu().double(), x.double(), d.double(), **okw)
+    dens, rgb, aux, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+    e_rgb = (rgb.cpu() - rr).abs().max().item()
+    e_den = ((dens.reshape(-1).cpu() - rd[:, 0]).abs() / (1 + rd[:, 0].abs())).max().item()
+    x_rgb = (rgb.cpu().double() - er).abs().max().item()
+    e_aux = max((aux[k].cpu() - raux[k]).abs().max().item() for k in aux)
+    print(f"ref-nerf bf16 {kw}: rgb {e_rgb:.2e} density {e_den:.2e} aux {e_aux:.2e} vs bf16 oracle; rgb {x_rgb:.2e} vs exact")
+    assert e_rgb < 4e-3 and e_den < 4e-3 and x_rgb < 5e-2
+    assert e_aux < 5e-2  # normals are ratios of bf16-operand input-gradients
+    g_d = torch.randn(m, generator=gen).float()
+    g_c = torch.randn(m, 3, generator=gen).float()
+    g_a = {"normal_mse": torch.rand(m, generator=gen).float(), "neg_normal": torch.rand(m, generator=gen).float()}
+    loss = (rd[:, 0] * g_d).sum() + (rr * g_c).sum() + sum((raux[k] * g_a[k]).sum() for k in g_a)
+    (g_ref,) = torch.autograd.grad(loss, f32)
+    grad = torch.zeros_like(flat)
+    model.backward(ctx, g_d.cuda(), g_c.cuda(), {k: v.cuda() for k, v in g_a.items()}, grad)
+    rel = ((grad.cpu() - g_ref).norm() / g_ref.norm()).item()
+    print(f"   gradient rel L2 err vs bf16-operand oracle {rel:.2e}")
+    assert rel < 3e-2
+
+
+def test_dense_precision_switch_is_scoped():
+    from learn_nerf import _lib as L
+    from learn_nerf import ops
+
+    lib = L.lib()
+    assert lib.lnrf_get_dense_precision() == 0
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(300, 70, generator=gen).cuda()
+    w = torch.randn(70, 40, generator=gen).cuda()
+    exact = x.double() @ w.double()
+    y32 = ops.dense_fwd(x, w, None, L.ACT_NONE)
+    with ops.dense_precision("bf16"):
+        assert lib.lnrf_get_dense_precision() == 1
+        y16 = ops.dense_fwd(x, w, None, L.ACT_NONE)
+    assert lib.lnrf_get_dense_precision() == 0
+    want16 = x.bfloat16().double() @ w.bfloat16().double()  # bf16-rounded operands, exact accumulate
+    assert (y32.double() - exact).abs().max().item() < 1e-4
+    assert (y16.double() - want16).abs().max().item() < 1e-4       # fp32 accumulation of exact bf16 products
+    assert (y16.double() - exact).abs().max().item() > 1e-3        # and it really is a different arithmetic
+    with pytest.raises(ValueError):
+        with ops.dense_precision("fp16"):
+            pass
+    assert lib.lnrf_set_dense_precision(7) < 0 and b"precision" in lib.lnrf_last_error()
