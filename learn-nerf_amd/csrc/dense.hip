@@ -2,12 +2,17 @@
 // fp32 products, fp32 accumulate).  This is the model-agnostic / exact-precision path:
 // flax.linen.Dense as used at learn_nerf/model.py:51-60, instant_ngp.py:47-53, ref_nerf.py:97-107,
 // plus sinusoidal_emb (model.py:65-77).  The performance path for NeRFModel is nerf_mlp.hip.
+#include <cstdint>
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace lnrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // operand precision of the dense path (lnrf_set_dense_precision): thread-local like lnrf_last_error
 static thread_local int g_dense_bf16 = 0;
@@ -150,6 +155,184 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+// Large-problem variant: 128x128 output tile, 4 waves x (2x2) 32x32 MFMA tiles, operands fetched as float4 along
+// their contiguous dimension (the caller guarantees 16-byte alignment and sizes that are multiples of 4 along
+// it).  A_FAST_R: A(i, r) contiguous in r (activations, row-major) else in i (X^T of the weight gradient);
+// B_FAST_R: B(r, j) contiguous in r (W^T of the input gradient) else in j (W, dy).  The generic kernel above
+// spends ~15 instructions per operand element on address arithmetic and scalar staging, which caps it at
+// ~60 (f32) / ~100 (bf16) TFLOP/s; this one moves 4 elements per load.
+constexpr int BI = 128, BJ = 128;
+template <bool BF16, bool A_FAST_R, bool B_FAST_R>
+__global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__ a, int64_t lda,
+                                                       const float* __restrict__ b, int64_t ldb,
+                                                       float* __restrict__ c, int64_t ldc,
+                                                       const float* __restrict__ bias, int act, int mode, int64_t I,
+                                                       int J, int64_t R, int64_t r_per_split) {
+  constexpr int KC = BF16 ? 32 : 16;                 // reduction depth per chunk
+  constexpr int NV = (BI * KC / 4) / 256;            // float4 per thread and operand
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[BF16 ? BI : 1][KC + 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Bh[BF16 ? BJ : 1][KC + 8];
+  __shared__ float As[BF16 ? 1 : BI][KC + 1];
+  __shared__ float Bs[BF16 ? 1 : KC][BJ + 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * BI;
+  const int j0 = blockIdx.y * BJ;
+  const int64_t r_begin = (int64_t)blockIdx.z * r_per_split;
+  const int64_t r_end = r_begin + r_per_split < R ? r_begin + r_per_split : R;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[x][y][q] = 0.0f;
+
+  float4 ra[NV], rb[NV];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // element (row, k) of an operand tile: row = i or j (0..127), k = 0..KC-1
+  // branch-free: out-of-range vectors read element 0 and are zeroed afterwards (a guarded load makes the
+  // compiler wait for every load separately)
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int v = q * 256 + tid;
+      int64_t ao, bo;
+      bool aok, bok;
+      if (A_FAST_R) {
+        const int row = v / (KC / 4), k4 = (v % (KC / 4)) * 4;
+        const int64_t gi = i0 + row, gr = r0 + k4;
+        aok = gi < I && gr < r_end;
+        ao = gi * lda + gr;
+      } else {
+        const int k = v / (BI / 4), row4 = (v % (BI / 4)) * 4;
+        const int64_t gi = i0 + row4, gr = r0 + k;
+        aok = gi < I && gr < r_end;
+        ao = gr * lda + gi;
+      }
+      if (B_FAST_R) {
+        const int row = v / (KC / 4), k4 = (v % (KC / 4)) * 4;
+        const int gj = j0 + row;
+        const int64_t gr = r0 + k4;
+        bok = gj < J && gr < r_end;
+        bo = (int64_t)gj * ldb + gr;
+      } else {
+        const int k = v / (BJ / 4), row4 = (v % (BJ / 4)) * 4;
+        const int gj = j0 + row4;
+        const int64_t gr = r0 + k;
+        bok = gj < J && gr < r_end;
+        bo = gr * ldb + gj;
+      }
+      const float4 av = *reinterpret_cast<const float4*>(a + (aok ? ao : 0));
+      const float4 bv = *reinterpret_cast<const float4*>(b + (bok ? bo : 0));
+      ra[q] = aok ? av : zero4;
+      rb[q] = bok ? bv : zero4;
+    }
+  };
+  auto put = [&](auto is_a, int row, int k, float val) {
+    if constexpr (decltype(is_a)::value) {
+      if constexpr (BF16) Ah[row][k] = (__bf16)val; else As[row][k] = val;
+    } else {
+      if constexpr (BF16) Bh[row][k] = (__bf16)val; else Bs[k][row] = val;
+    }
+  };
+  auto stage = [&]() {
+    std::true_type is_a;
+    std::false_type is_b;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int v = q * 256 + tid;
+      const float va[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w};
+      const float vb[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+      if (A_FAST_R) {
+        const int row = v / (KC / 4), k4 = (v % (KC / 4)) * 4;
+        if constexpr (BF16) {  // four consecutive k of one row: one 8-byte LDS store
+          const bf16x4 hv = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
+          *reinterpret_cast<bf16x4*>(&Ah[row][k4]) = hv;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) put(is_a, row, k4 + e, va[e]);
+        }
+      } else {
+        const int k = v / (BI / 4), row4 = (v % (BI / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) put(is_a, row4 + e, k, va[e]);
+      }
+      if (B_FAST_R) {
+        const int row = v / (KC / 4), k4 = (v % (KC / 4)) * 4;
+        if constexpr (BF16) {
+          const bf16x4 hv = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
+          *reinterpret_cast<bf16x4*>(&Bh[row][k4]) = hv;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) put(is_b, row, k4 + e, vb[e]);
+        }
+      } else {
+        const int k = v / (BJ / 4), row4 = (v % (BJ / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) put(is_b, row4 + e, k, vb[e]);
+      }
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += KC) {
+    stage();
+    __syncthreads();
+    if (r0 + KC < r_end) fetch(r0 + KC);
+    if constexpr (BF16) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        bf16x8 av[2], bv[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+          av[x] = *reinterpret_cast<const bf16x8*>(&Ah[wr * 64 + x * 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          bv[y] = *reinterpret_cast<const bf16x8*>(&Bh[wc * 64 + y * 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[x], bv[y], acc[x][y], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; ++kk) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) av[x] = As[wr * 64 + x * 32 + (lane & 31)][kk * 2 + (lane >> 5)];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) bv[y] = Bs[kk * 2 + (lane >> 5)][wc * 64 + y * 32 + (lane & 31)];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const int col = j0 + wc * 64 + y * 32 + (lane & 31);
+    if (col >= J) continue;
+    const float bvv = (bias && mode == 0) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = i0 + wr * 64 + x * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < I) {
+          float* dst = c + row * ldc + col;
+          if (mode == 0) *dst = act_apply(acc[x][y][q] + bvv, act);
+          else if (mode == 1) *dst += acc[x][y][q];
+          else atomicAdd(dst, acc[x][y][q]);
+        }
+      }
+  }
+}
+
 __global__ void col_sum_kernel(const float* __restrict__ g, int64_t ldg, int64_t m, int n,
                                float* __restrict__ out) {
   // out[j] += sum_i g[i][j]; grid.x tiles rows (1024 per block), threads stride columns
@@ -197,11 +380,45 @@ __global__ void sinusoidal_emb_kernel(const float* __restrict__ x, int64_t ldx, 
 
 using namespace lnrf;
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r,
                        int64_t sb_j, float* c, int64_t ldc, const float* bias, int act, int mode,
                        int64_t I, int J, int64_t R, int splits, hipStream_t stream) {
   if (I == 0 || J == 0) return LNRF_OK;
   if (splits < 1) splits = 1;
+  // vectorised 128x128 kernel: both operands contiguous along one of their dimensions, 16-byte aligned rows,
+  // extents along the contiguous dimensions multiples of 4, and enough work to fill 128-wide tiles
+  const bool a_fast_r = sa_r == 1;
+  const bool b_fast_r = sb_r == 1, b_fast_j = sb_j == 1;
+  const int64_t lda = sa_i, ldb = b_fast_r ? sb_j : sb_r;
+  // (measured: +15-30 % over the generic kernel when A is r-contiguous; the i-contiguous A of the weight gradient
+  // needs transposing scalar LDS stores whose bank conflicts make it slower than the generic kernel, so it stays there)
+  const bool big = a_fast_r && (b_fast_r || b_fast_j) && aligned16(a) && aligned16(b) && lda % 4 == 0 &&
+                   ldb % 4 == 0 && R % 4 == 0 && (b_fast_r || J % 4 == 0) &&
+                   I >= 64 && J >= 64 && R >= 32;
+  if (big) {
+    const int kc = g_dense_bf16 ? 32 : 16;
+    int64_t per = (R + splits - 1) / splits;
+    per = ((per + kc - 1) / kc) * kc;
+    if (per % 4 != 0) per = ((per + 3) / 4) * 4;
+    int nsplit = (int)((R + per - 1) / per);
+    if (nsplit < 1) nsplit = 1;
+    dim3 grid((unsigned)((I + BI - 1) / BI), (unsigned)((J + BJ - 1) / BJ), (unsigned)nsplit);
+#define LNRF_BIG(BF, AR, BR)                                                                                       \
+  hipLaunchKernelGGL((gemm_big_kernel<BF, AR, BR>), grid, dim3(256), 0, stream, a, lda, b, ldb, c, ldc, bias, act, \
+                     mode, I, J, R, per)
+    const bool br = !b_fast_j;
+    if (g_dense_bf16) {
+      if (br) LNRF_BIG(true, true, true); else LNRF_BIG(true, true, false);
+    } else {
+      if (br) LNRF_BIG(false, true, true); else LNRF_BIG(false, true, false);
+    }
+#undef LNRF_BIG
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gemm_big");
+    return LNRF_OK;
+  }
   int64_t per = (R + splits - 1) / splits;
   per = ((per + RC - 1) / RC) * RC;
   if (per < RC) per = RC;

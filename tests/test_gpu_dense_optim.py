@@ -101,3 +101,36 @@ def test_adam_and_sq_norm(n):
     ops.sq_norm_into(pd, out)
     ref = (pd.cpu().double() ** 2).sum().item()
     assert abs(out.item() - ref) <= 1e-5 * ref
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("m,k,n", [(1000, 256, 256), (777, 316, 256), (4101, 64, 128), (130, 280, 132)])
+def test_vectorised_gemm_all_layouts(precision, m, k, n):
+    """
+    The 128x128 float4 kernel (taken for aligned operands with >= 64 rows / columns): forward (A contiguous in r,
+    B in j), input gradient (A in r, B in r), weight gradient (A in i, B in j, split-K atomics), ragged tile
+    edges, both operand precisions.  bf16 reference = the same products with bf16-rounded operands.
+    """
+    from learn_nerf import _lib as L
+    from learn_nerf import ops
+
+    gen = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=gen)
+    w = torch.randn(k, n, generator=gen) / k ** 0.5
+    b = torch.randn(n, generator=gen)
+    gy = torch.randn(m, n, generator=gen)
+    rnd = (lambda t: t.bfloat16().double()) if precision == "bf16" else (lambda t: t.double())
+    tol = dict(atol=1e-4, rtol=1e-4)
+    with ops.dense_precision(precision):
+        y = ops.dense_fwd(x.cuda(), w.cuda(), b.cuda(), L.ACT_RELU)
+        gx = ops.dense_bwd_input(gy.cuda(), w.cuda())
+        gw = torch.zeros(k, n, device="cuda")
+        gb = torch.zeros(n, device="cuda")
+        ops.dense_bwd_weight(x.cuda(), gy.cuda(), gw, gb)
+    assert torch.allclose(y.cpu().double(), torch.relu(rnd(x) @ rnd(w) + b.double()), **tol)
+    assert torch.allclose(gx.cpu().double(), rnd(gy) @ rnd(w).T, **tol)
+    ref_gw = rnd(x).T @ rnd(gy)
+    assert ((gw.cpu().double() - ref_gw).abs().max() / ref_gw.abs().max()).item() < 1e-5
+    assert torch.allclose(gb.cpu().double(), gy.double().sum(0), atol=1e-3, rtol=1e-4)
+    if precision == "bf16":  # and it is not the exact product
+        assert (y.cpu().double() - torch.relu(x.double() @ w.double() + b.double())).abs().max().item() > 1e-3
