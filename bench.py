@@ -94,8 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="nerf", choices=["nerf", "ngp"],
-                    help="nerf = BASELINE configs[1] (the metric's config, default); ngp = configs[2] hash-grid path")
+    ap.add_argument("--workload", default="nerf", choices=["nerf", "ngp", "refnerf"],
+                    help="nerf = BASELINE configs[1] (the metric's config, default); ngp = configs[2] hash-grid path; "
+                         "refnerf = configs[3] RefNERFModel on the generic dense path (no roofline model: reported as null)")
     ap.add_argument("--table_log2", type=int, default=19, help="ngp: log2 of the hash table size (configs[2]: 19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -138,6 +139,12 @@ def main():
 
         loop = TrainLoop(ngp(6), ngp(16), init_rng=0, lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, adam_eps=1e-15,
                          adam_b1=0.9, adam_b2=0.99, device=device)
+    elif args.workload == "refnerf":
+        from learn_nerf.ref_nerf import RefNERFModel
+
+        loop = TrainLoop(RefNERFModel(sh_degree=4, precision=args.precision),
+                         RefNERFModel(sh_degree=4, precision=args.precision), init_rng=0, lr=1e-4, coarse_ts=COARSE,
+                         fine_ts=FINE, device=device)
     else:
         loop = TrainLoop(NeRFModel(precision=args.precision), NeRFModel(precision=args.precision), init_rng=0,
                          lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, device=device)
@@ -236,9 +243,11 @@ def main():
             ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype="bf16" if args.precision == "bf16" else "f32",
             data="synthetic",
-            config=dict(workload="vanilla NeRF coarse64+fine128 train step (BASELINE.json configs[1])"
-                        if args.workload == "nerf" else
-                        f"instant_ngp hash-grid L=6/16, T=2^{args.table_log2} train step (BASELINE.json configs[2])",
+            config=dict(workload={"nerf": "vanilla NeRF coarse64+fine128 train step (BASELINE.json configs[1])",
+                                  "ngp": f"instant_ngp hash-grid L=6/16, T=2^{args.table_log2} train step "
+                                         "(BASELINE.json configs[2])",
+                                  "refnerf": "ref_nerf.py RefNERFModel sh_degree 4 train step incl. normal losses "
+                                             "(BASELINE.json configs[3])"}[args.workload],
                         rays_per_gpu=n, coarse_samples=COARSE, fine_samples=FINE, global_batch_rays=world * n,
                         parallelism=f"dp{world}", precision=args.precision + " MFMA, fp32 accumulate/master weights"
                         if args.precision == "bf16" else "fp32 (f32 MFMA)"),
