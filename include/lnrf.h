@@ -158,6 +158,19 @@ int lnrf_act_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int32_t act
 int lnrf_dense_bwd_input(const float* gy, int64_t ldgy, const float* w, float* gx, int64_t ldgx,
                          int32_t accumulate, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
 
+/* lnrf_dense_bwd_input fused with the activation backward of the layer below:
+ * gx[i][c] (+)= (sum_r gy[i][r] w[c][r]) * act'(y_below[i][c]) for c < n_gated (act' expressed through the activation's
+ * OUTPUT, as lnrf_act_bwd), plain input gradient for the other columns (e.g. the x_emb part of a concatenated input).
+ * Saves one read-modify-write pass over gx per layer. */
+int lnrf_dense_bwd_input_gated(const float* gy, int64_t ldgy, const float* w, const float* y_below, int64_t ldy,
+                               int32_t act_below, int32_t n_gated, float* gx, int64_t ldgx, int32_t accumulate,
+                               int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
+/* lnrf_dense_fwd whose result is multiplied by act_gate'(y_gate[i][j]): the masked forward product of the
+ * second-order (normal) chain of ref_nerf.py:38-43, tbar_l = relu'(h_l) * (tbar_{l-1} W_l). */
+int lnrf_dense_fwd_gated(const float* x, int64_t ldx, const float* w, const float* b, int32_t act,
+                         const float* y_gate, int64_t ldg, int32_t act_gate, float* y, int64_t ldy, int64_t m,
+                         int32_t k, int32_t n, lnrf_stream_t stream);
+
 /* g_w[K,N] += x[M,K]^T @ g_y[M,N];  g_b[N] += sum_m g_y (g_b may be NULL).
  * x == NULL and gw == NULL: bias gradient only. */
 int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gw,

@@ -90,6 +90,10 @@ PROTOTYPES = {
     "lnrf_ngp_mlp_pack": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P]),
     "lnrf_ngp_mlp_fwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, c_int64, _P, _P, _P]),
     "lnrf_ngp_mlp_bwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "lnrf_dense_bwd_input_gated": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, c_int32,
+                                             c_int64, c_int32, c_int32, _P]),
+    "lnrf_dense_fwd_gated": (c_int32, [_P, c_int64, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_int64, c_int64,
+                                       c_int32, c_int32, _P]),
     "lnrf_set_dense_precision": (c_int32, [c_int32]),
     "lnrf_get_dense_precision": (c_int32, []),
     "lnrf_adam_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,

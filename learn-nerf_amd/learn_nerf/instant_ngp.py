@@ -282,8 +282,7 @@ class InstantNGPModel(ModelBase):
             gy = ops.act_bwd_(g_rgb.reshape(-1, 3).clone(), ctx["rgb"], L.ACT_TANH)
             for i in reversed(range(self.color_layers)):
                 ops.dense_bwd_weight(cacts[i], gy, G[li][0], G[li][1])
-                gh = ops.dense_bwd_input(gy, W[li][0])
-                gy = ops.act_bwd_(gh, cacts[i], L.ACT_RELU)
+                gy = ops.dense_bwd_input(gy, W[li][0], gate=cacts[i])
                 li -= 1
             ops.dense_bwd_weight(cat, gy, G[li][0], G[li][1])
             gcat = ops.dense_bwd_input(gy, W[li][0])  # [M, 24 + density_dim]
@@ -293,13 +292,11 @@ class InstantNGPModel(ModelBase):
             li -= 1
             h = acts[-1]
             ops.dense_bwd_weight(h, g_out, G[li][0], G[li][1])
-            gh = ops.dense_bwd_input(g_out, W[li][0])
-            gy = ops.act_bwd_(gh, h, L.ACT_RELU)
+            gy = ops.dense_bwd_input(g_out, W[li][0], gate=h)
             li -= 1
             for i in reversed(range(1, self.density_layers)):
                 ops.dense_bwd_weight(acts[i - 1], gy, G[li][0], G[li][1])
-                gh = ops.dense_bwd_input(gy, W[li][0])
-                gy = ops.act_bwd_(gh, acts[i - 1], L.ACT_RELU)
+                gy = ops.dense_bwd_input(gy, W[li][0], gate=acts[i - 1])
                 li -= 1
             # Dense_0: input is the feature-major encoding
             hd = self.hidden_dim
@@ -373,7 +370,7 @@ class InstantNGPRefNERFModel(ModelBase):
         # analytic normal: c1 = -e0, c0 = relu'(h0) * (c1 W1^T), g_enc = W0 c0, nraw = (d enc/dx)^T g_enc
         c1 = torch.zeros((m, dd), dtype=F32, device=dev)
         c1[:, 0] = -1.0
-        c0 = ops.act_bwd_(ops.dense_bwd_input(c1, W[1][0]), h0, L.ACT_RELU)
+        c0 = ops.dense_bwd_input(c1, W[1][0], gate=h0)
         g_enc_t = torch.empty((lf, m), dtype=F32, device=dev)
         ops.gemm(W[0][0], hd, 1, c0, 1, hd, g_enc_t, m, lf, m, hd)
         nraw = ops.hashgrid_input_grad(desc, tables, x, g_enc_t)
@@ -413,7 +410,7 @@ class InstantNGPRefNERFModel(ModelBase):
         gy = g_do
         for i in reversed(range(self.color_layers)):
             ops.dense_bwd_weight(cacts[i], gy, G[li][0], G[li][1])
-            gy = ops.act_bwd_(ops.dense_bwd_input(gy, W[li][0]), cacts[i], L.ACT_RELU)
+            gy = ops.dense_bwd_input(gy, W[li][0], gate=cacts[i])
             li -= 1
         ops.dense_bwd_weight(dir_in, gy, G[li][0], G[li][1])
         g_dir_in = ops.dense_bwd_input(gy, W[li][0])
@@ -422,7 +419,7 @@ class InstantNGPRefNERFModel(ModelBase):
         # (i) first-order path through Dense_1, Dense_0 and the tables
         g_out = g_dir_in[:, :dd]
         ops.dense_bwd_weight(h0, g_out, G[1][0], G[1][1])
-        gy0 = ops.act_bwd_(ops.dense_bwd_input(g_out, W[1][0]), h0, L.ACT_RELU)
+        gy0 = ops.dense_bwd_input(g_out, W[1][0], gate=h0)
         ops.gemm(ctx["enc_t"], m, 1, gy0, hd, 1, G[0][0], hd, lf, hd, m, mode=2)
         ops.bias_grad(gy0, G[0][1])
         g1_t = torch.empty((lf, m), dtype=F32, device=dev)

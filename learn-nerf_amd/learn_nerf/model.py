@@ -280,8 +280,7 @@ class NeRFModel(ModelBase):
         i_rgb, i_col, i_den = nl - 1, nl - 2, nl - 3
         gy = ops.act_bwd_(g_rgb.reshape(-1, 3).clone(), ctx["rgb"], L.ACT_TANH)
         ops.dense_bwd_weight(h_col, gy, *G[i_rgb])
-        gh = ops.dense_bwd_input(gy, W[i_rgb])
-        gy = ops.act_bwd_(gh, h_col, L.ACT_RELU)
+        gy = ops.dense_bwd_input(gy, W[i_rgb], gate=h_col)  # ReLU backward of Dense_10 fused in
         ops.dense_bwd_weight(cat_d, gy, *G[i_col])
         gz = ops.dense_bwd_input(gy, W[i_col][:hd])
         gd = ops.act_bwd_(g_density.reshape(-1, 1).clone(), ctx["density"], L.ACT_SOFTPLUS)
@@ -293,14 +292,12 @@ class NeRFModel(ModelBase):
         for i in reversed(range(self.mid_layers)):
             inp = cat_x if i == 0 else acts[self.input_layers + i - 1]
             ops.dense_bwd_weight(inp, gy, *G[li])
-            gh = ops.dense_bwd_input(gy, W[li][:hd])
             prev = cat_x[:, :hd] if i == 0 else acts[self.input_layers + i - 1]
-            gy = ops.act_bwd_(gh, prev, L.ACT_RELU)
+            gy = ops.dense_bwd_input(gy, W[li][:hd], gate=prev)  # input gradient + ReLU backward of the layer below
             li -= 1
         for i in reversed(range(self.input_layers)):
             inp = cat_x[:, hd:] if i == 0 else acts[i - 1]
             ops.dense_bwd_weight(inp, gy, *G[li])
             if i > 0:
-                gh = ops.dense_bwd_input(gy, W[li])
-                gy = ops.act_bwd_(gh, acts[i - 1], L.ACT_RELU)
+                gy = ops.dense_bwd_input(gy, W[li], gate=acts[i - 1])
             li -= 1

@@ -199,14 +199,21 @@ def sinusoidal_emb_into(x: torch.Tensor, freqs: int, out: torch.Tensor, col_off:
 
 
 def dense_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+              gate_act: int = L.ACT_RELU) -> torch.Tensor:
+    """act(x @ w + b); with `gate` ([m, n], an activation OUTPUT) the result is multiplied by gate_act'(gate)."""
     m, k = x.shape
     k2, n = w.shape
     assert k == k2 and w.is_contiguous()
     if out is None:
         out = torch.empty((m, n), dtype=F32, device=_dev(x))
-    L.check(L.lib().lnrf_dense_fwd(_vptr(x), _ld(x), L.ptr(w), L.ptr(b), act, _vptr(out), _ld(out), m, k, n,
-                                   L.stream()), "dense_fwd")
+    if gate is None:
+        L.check(L.lib().lnrf_dense_fwd(_vptr(x), _ld(x), L.ptr(w), L.ptr(b), act, _vptr(out), _ld(out), m, k, n,
+                                       L.stream()), "dense_fwd")
+    else:
+        assert gate.shape == (m, n)
+        L.check(L.lib().lnrf_dense_fwd_gated(_vptr(x), _ld(x), L.ptr(w), L.ptr(b), act, _vptr(gate), _ld(gate),
+                                             gate_act, _vptr(out), _ld(out), m, k, n, L.stream()), "dense_fwd_gated")
     return out
 
 
@@ -217,15 +224,27 @@ def act_bwd_(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
 
 
 def dense_bwd_input(gy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
-                    accumulate: bool = False) -> torch.Tensor:
+                    accumulate: bool = False, gate: Optional[torch.Tensor] = None,
+                    gate_act: int = L.ACT_RELU) -> torch.Tensor:
+    """
+    gy @ w.T (added to `out` if accumulate).  With `gate` ([m, g <= k], the OUTPUT of the activation that
+    produced the first g input columns) those columns are multiplied by gate_act'(gate): the activation backward
+    of the layer below fused into the GEMM (lnrf_dense_bwd_input_gated).
+    """
     m, n = gy.shape
     k, n2 = w.shape
     assert n == n2
     if out is None:
         out = torch.empty((m, k), dtype=F32, device=_dev(gy))
         accumulate = False
-    L.check(L.lib().lnrf_dense_bwd_input(_vptr(gy), _ld(gy), L.ptr(w), _vptr(out), _ld(out),
-                                         1 if accumulate else 0, m, k, n, L.stream()), "dense_bwd_input")
+    if gate is None:
+        L.check(L.lib().lnrf_dense_bwd_input(_vptr(gy), _ld(gy), L.ptr(w), _vptr(out), _ld(out),
+                                             1 if accumulate else 0, m, k, n, L.stream()), "dense_bwd_input")
+    else:
+        assert gate.shape[0] == m and gate.shape[1] <= k
+        L.check(L.lib().lnrf_dense_bwd_input_gated(_vptr(gy), _ld(gy), L.ptr(w), _vptr(gate), _ld(gate), gate_act,
+                                                   gate.shape[1], _vptr(out), _ld(out), 1 if accumulate else 0, m,
+                                                   k, n, L.stream()), "dense_bwd_input_gated")
     return out
 
 

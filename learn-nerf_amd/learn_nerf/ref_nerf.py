@@ -131,11 +131,12 @@ class RefNERFModel(RefNERFBase):
             c[ns - 1] = top
             g_cat = None
             for l in range(ns - 1, 0, -1):
-                gh = ops.dense_bwd_input(c[l], W[l][0])  # [M, fan_in(l)]
+                # input gradient with the ReLU backward of the layer below fused in (first hd columns)
+                gh = ops.dense_bwd_input(c[l], W[l][0], gate=h[l - 1])  # [M, fan_in(l)]
                 if l == self.input_layers:  # Dense_5 consumed [h4, x_emb]
                     g_cat = gh
                     gh = gh[:, :hd]
-                c[l - 1] = ops.act_bwd_(gh, h[l - 1], L.ACT_RELU)
+                c[l - 1] = gh
             if g_cat is None:  # no mid layers: should not happen with the reference architecture
                 g_cat = torch.zeros((m, hd + xe_w), dtype=F32, device=dev)
             ops.dense_bwd_input(c[0], W[0][0], out=g_cat[:, hd:], accumulate=True)  # x_emb also feeds Dense_0
@@ -169,7 +170,7 @@ class RefNERFModel(RefNERFBase):
             g_do, g_sp, g_df = ops.refnerf_color_bwd(ctx["dir_out"], ctx["spectral"], ctx["diffuse"],
                                                      g_rgb.reshape(-1, 3).contiguous())
             ops.dense_bwd_weight(ctx["hcol"], g_do, G[ns + 1][0], G[ns + 1][1])
-            gy = ops.act_bwd_(ops.dense_bwd_input(g_do, W[ns + 1][0]), ctx["hcol"], L.ACT_RELU)
+            gy = ops.dense_bwd_input(g_do, W[ns + 1][0], gate=ctx["hcol"])
             ops.dense_bwd_weight(dir_in, gy, G[ns][0], G[ns][1])
             g_dir_in = ops.dense_bwd_input(gy, W[ns][0])  # [M, hd + sh^2 + 1]
             u = ops.refnerf_head_bwd(dir_in, ctx["nraw"], d, self.sh_degree, g_density.reshape(-1).contiguous(), g_df,
@@ -181,8 +182,7 @@ class RefNERFModel(RefNERFBase):
                 inp = cat_x if l == il else (cat_x[:, hd:] if l == 0 else h[l - 1])
                 ops.dense_bwd_weight(inp, gy, G[l][0], G[l][1])
                 if l > 0:
-                    gh = ops.dense_bwd_input(gy, W[l][0][:hd])
-                    gy = ops.act_bwd_(gh, h[l - 1], L.ACT_RELU)
+                    gy = ops.dense_bwd_input(gy, W[l][0][:hd], gate=h[l - 1])
         with _prof.section(f"{self.tag}_normal_bwd"):
             # (ii) second-order path: the normal pass is a chain in the SAME kernels with the ReLU masks
             # fixed (ReLU'' = 0 a.e.): ge = W_0 c_0 + W_5[hd:] c_5, c_{l-1} = mask_{l-1} * (W_l c_l).
@@ -192,13 +192,12 @@ class RefNERFModel(RefNERFBase):
             ops.sinusoidal_emb_jvp_into(x, self.x_freqs, u, tc, hd)
             ubar_e = tc[:, hd:]
             ops.dense_bwd_weight(ubar_e, c[0], G[0][0], None)
-            cbar = ops.dense_fwd(ubar_e, W[0][0], None, L.ACT_NONE)
+            # tbar_l = relu'(h_l) * (tbar_{l-1} W_l): the mask is applied in the GEMM epilogue (gated forward);
+            # the product that feeds Dense_{il} is written straight into its [tbar, ubar_e] buffer
+            tbar = ops.dense_fwd(ubar_e, W[0][0], None, L.ACT_NONE, out=tc[:, :hd] if il == 1 else None, gate=h[0])
             for l in range(1, ns):
-                if l == il:
-                    tb = ops.act_bwd_(tc[:, :hd].copy_(cbar), h[l - 1], L.ACT_RELU)
-                    tb = tc  # Dense_5 sees [tbar_4, ubar_e]
-                else:
-                    tb = ops.act_bwd_(cbar, h[l - 1], L.ACT_RELU)
+                tb = tc if l == il else tbar  # Dense_5 sees [tbar_4, ubar_e]
                 ops.dense_bwd_weight(tb, c[l], G[l][0], None)
                 if l < ns - 1:
-                    cbar = ops.dense_fwd(tb, W[l][0], None, L.ACT_NONE)
+                    tbar = ops.dense_fwd(tb, W[l][0], None, L.ACT_NONE, out=tc[:, :hd] if l + 1 == il else None,
+                                         gate=h[l])

@@ -134,3 +134,29 @@ def test_vectorised_gemm_all_layouts(precision, m, k, n):
     assert torch.allclose(gb.cpu().double(), gy.double().sum(0), atol=1e-3, rtol=1e-4)
     if precision == "bf16":  # and it is not the exact product
         assert (y.cpu().double() - torch.relu(x.double() @ w.double() + b.double())).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("m,k,n,g", [(300, 256, 256, 256), (1000, 316, 256, 256), (77, 40, 64, 40), (513, 64, 3, 64)])
+def test_gated_input_gradient_and_gated_forward(m, k, n, g):
+    """lnrf_dense_bwd_input_gated / lnrf_dense_fwd_gated = GEMM followed by the activation backward of the layer
+    below (first g columns), in one kernel; both GEMM kernels, plain and accumulating."""
+    from learn_nerf import _lib as L
+    from learn_nerf import ops
+
+    gen = torch.Generator().manual_seed(m + k)
+    w = (torch.randn(k, n, generator=gen) / k ** 0.5).cuda()
+    gy = torch.randn(m, n, generator=gen).cuda()
+    h_below = torch.relu(torch.randn(m, g, generator=gen)).cuda()  # ReLU output: ~half zeros
+    want = ops.dense_bwd_input(gy, w)
+    want[:, :g] = ops.act_bwd_(want[:, :g].contiguous(), h_below, L.ACT_RELU)
+    got = ops.dense_bwd_input(gy, w, gate=h_below)
+    assert torch.equal(got, want)
+    base = torch.randn(m, k, generator=gen).cuda()
+    acc = ops.dense_bwd_input(gy, w, out=base.clone(), accumulate=True, gate=h_below)
+    assert torch.allclose(acc, base + want, atol=1e-5, rtol=1e-5)
+    # gated forward with a tanh gate: y * (1 - t^2)
+    x = torch.randn(m, k, generator=gen).cuda()
+    t = torch.tanh(torch.randn(m, n, generator=gen)).cuda()
+    b = torch.randn(n, generator=gen).cuda()
+    y = ops.dense_fwd(x, w, b, L.ACT_NONE, gate=t, gate_act=L.ACT_TANH)
+    assert torch.allclose(y, ops.dense_fwd(x, w, b, L.ACT_NONE) * (1 - t * t), atol=1e-5, rtol=1e-5)
