@@ -173,6 +173,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // spends ~15 instructions per operand element on address arithmetic and scalar staging, which caps it at
 // ~60 (f32) / ~100 (bf16) TFLOP/s; this one moves 4 elements per load.
 constexpr int BI = 128, BJ = 128;
+// bf16 LDS image of an operand tile: [row][k] with the 16-byte chunks (8 k) of a row XOR-swizzled by bits 2..3 of the
+// row.  The operand that is contiguous along its row dimension in memory arrives as float4 = 4 ROWS at one k, i.e.
+// as scalar 2-byte LDS stores 4 rows apart: without the swizzle they fall on 4 banks (8-way conflict).
+__device__ __forceinline__ int swz(int row, int k) { return ((((k >> 3) ^ (row >> 2)) & 3) << 3) | (k & 7) | (k & ~31); }
 template <bool BF16, bool A_FAST_R, bool B_FAST_R>
 __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__ a, int64_t lda,
                                                        const float* __restrict__ b, int64_t ldb,
@@ -244,9 +248,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
   };
   auto put = [&](auto is_a, int row, int k, float val) {
     if constexpr (decltype(is_a)::value) {
-      if constexpr (BF16) Ah[row][k] = (__bf16)val; else As[row][k] = val;
+      if constexpr (BF16) Ah[row][swz(row, k)] = (__bf16)val; else As[row][k] = val;
     } else {
-      if constexpr (BF16) Bh[row][k] = (__bf16)val; else Bs[k][row] = val;
+      if constexpr (BF16) Bh[row][swz(row, k)] = (__bf16)val; else Bs[k][row] = val;
     }
   };
   auto stage = [&]() {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
         const int row = v / (KC / 4), k4 = (v % (KC / 4)) * 4;
         if constexpr (BF16) {  // four consecutive k of one row: one 8-byte LDS store
           const bf16x4 hv = {(__bf16)va[0], (__bf16)va[1], (__bf16)va[2], (__bf16)va[3]};
-          *reinterpret_cast<bf16x4*>(&Ah[row][k4]) = hv;
+          *reinterpret_cast<bf16x4*>(&Ah[row][swz(row, k4)]) = hv;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) put(is_a, row, k4 + e, va[e]);
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
         const int row = v / (KC / 4), k4 = (v % (KC / 4)) * 4;
         if constexpr (BF16) {
           const bf16x4 hv = {(__bf16)vb[0], (__bf16)vb[1], (__bf16)vb[2], (__bf16)vb[3]};
-          *reinterpret_cast<bf16x4*>(&Bh[row][k4]) = hv;
+          *reinterpret_cast<bf16x4*>(&Bh[row][swz(row, k4)]) = hv;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) put(is_b, row, k4 + e, vb[e]);
@@ -298,10 +302,10 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
         bf16x8 av[2], bv[2];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
-          av[x] = *reinterpret_cast<const bf16x8*>(&Ah[wr * 64 + x * 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+          av[x] = *reinterpret_cast<const bf16x8*>(&Ah[wr * 64 + x * 32 + (lane & 31)][swz(wr * 64 + x * 32 + (lane & 31), 16 * ks + 8 * (lane >> 5))]);
 #pragma unroll
         for (int y = 0; y < 2; ++y)
-          bv[y] = *reinterpret_cast<const bf16x8*>(&Bh[wc * 64 + y * 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+          bv[y] = *reinterpret_cast<const bf16x8*>(&Bh[wc * 64 + y * 32 + (lane & 31)][swz(wc * 64 + y * 32 + (lane & 31), 16 * ks + 8 * (lane >> 5))]);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -433,14 +437,14 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
   if (splits < 1) splits = 1;
   // vectorised 128x128 kernel: both operands contiguous along one of their dimensions, 16-byte aligned rows,
   // extents along the contiguous dimensions multiples of 4, and enough work to fill 128-wide tiles
-  const bool a_fast_r = sa_r == 1;
+  const bool a_fast_r = sa_r == 1, a_fast_i = sa_i == 1 && !a_fast_r;
   const bool b_fast_r = sb_r == 1, b_fast_j = sb_j == 1;
-  const int64_t lda = sa_i, ldb = b_fast_r ? sb_j : sb_r;
-  // (measured: +15-30 % over the generic kernel when A is r-contiguous; the i-contiguous A of the weight gradient
-  // needs transposing scalar LDS stores whose bank conflicts make it slower than the generic kernel, so it stays there)
-  const bool big = a_fast_r && (b_fast_r || b_fast_j) && aligned16(a) && aligned16(b) && lda % 4 == 0 &&
-                   ldb % 4 == 0 && R % 4 == 0 && (b_fast_r || J % 4 == 0) &&
-                   I >= 64 && J >= 64 && R >= 32;
+  const int64_t lda = a_fast_r ? sa_i : sa_r, ldb = b_fast_r ? sb_j : sb_r;
+  // A contiguous in i (X^T of the weight gradient) only with bf16 operands, where the swizzled LDS image keeps the
+  // transposing stores nearly conflict-free; in f32 the generic kernel is as fast
+  const bool big = (a_fast_r || (a_fast_i && g_dense_bf16)) && (b_fast_r || b_fast_j) && aligned16(a) && aligned16(b) &&
+                   lda % 4 == 0 && ldb % 4 == 0 && (a_fast_r ? R % 4 == 0 : I % 4 == 0) &&
+                   (b_fast_r ? R % 4 == 0 : J % 4 == 0) && I >= 64 && J >= 64 && R >= 32;
   if (big) {
     const int kc = g_dense_bf16 ? 32 : 16;
     int64_t per = (R + splits - 1) / splits;
@@ -452,9 +456,10 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
 #define LNRF_BIG(BF, AR, BR)                                                                                       \
   hipLaunchKernelGGL((gemm_big_kernel<BF, AR, BR>), grid, dim3(256), 0, stream, a, lda, b, ldb, c, ldc, bias, act, \
                      mode, I, J, R, per, gate)
-    const bool br = !b_fast_j;
+    const bool ar = a_fast_r, br = !b_fast_j;
     if (g_dense_bf16) {
-      if (br) LNRF_BIG(true, true, true); else LNRF_BIG(true, true, false);
+      if (ar && br) LNRF_BIG(true, true, true); else if (ar) LNRF_BIG(true, true, false);
+      else if (br) LNRF_BIG(true, false, true); else LNRF_BIG(true, false, false);
     } else {
       if (br) LNRF_BIG(false, true, true); else LNRF_BIG(false, true, false);
     }
