@@ -177,7 +177,8 @@ constexpr int BI = 128, BJ = 128;
 // row.  The operand that is contiguous along its row dimension in memory arrives as float4 = 4 ROWS at one k, i.e.
 // as scalar 2-byte LDS stores 4 rows apart: without the swizzle they fall on 4 banks (8-way conflict).
 __device__ __forceinline__ int swz(int row, int k) { return ((((k >> 3) ^ (row >> 2)) & 3) << 3) | (k & 7) | (k & ~31); }
-template <bool BF16, bool A_FAST_R, bool B_FAST_R>
+// B_ALIGNED = false: B (a weight matrix inside a flat parameter vector) is only 4-byte aligned.
+template <bool BF16, bool A_FAST_R, bool B_FAST_R, bool B_ALIGNED = true>
 __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__ a, int64_t lda,
                                                        const float* __restrict__ b, int64_t ldb,
                                                        float* __restrict__ c, int64_t ldc,
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
         bo = gr * ldb + gj;
       }
       const float4 av = *reinterpret_cast<const float4*>(a + (aok ? ao : 0));
-      const float4 bv = *reinterpret_cast<const float4*>(b + (bok ? bo : 0));
+      float4 bv;
+      if constexpr (B_ALIGNED) bv = *reinterpret_cast<const float4*>(b + (bok ? bo : 0));
+      else __builtin_memcpy(&bv, b + (bok ? bo : 0), sizeof(float4));  // 4-byte aligned source
       ra[q] = aok ? av : zero4;
       rb[q] = bok ? bv : zero4;
     }
@@ -442,7 +445,8 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
   const int64_t lda = a_fast_r ? sa_i : sa_r, ldb = b_fast_r ? sb_j : sb_r;
   // A contiguous in i (X^T of the weight gradient) only with bf16 operands, where the swizzled LDS image keeps the
   // transposing stores nearly conflict-free; in f32 the generic kernel is as fast
-  const bool big = (a_fast_r || (a_fast_i && g_dense_bf16)) && (b_fast_r || b_fast_j) && aligned16(a) && aligned16(b) &&
+  const bool b_al = aligned16(b);  // weights inside a flat parameter vector may start at any float
+  const bool big = (a_fast_r || (a_fast_i && g_dense_bf16)) && (b_fast_r || b_fast_j) && aligned16(a) &&
                    lda % 4 == 0 && ldb % 4 == 0 && (a_fast_r ? R % 4 == 0 : I % 4 == 0) &&
                    (b_fast_r ? R % 4 == 0 : J % 4 == 0) && I >= 64 && J >= 64 && R >= 32;
   if (big) {
@@ -453,9 +457,15 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
     int nsplit = (int)((R + per - 1) / per);
     if (nsplit < 1) nsplit = 1;
     dim3 grid((unsigned)((I + BI - 1) / BI), (unsigned)((J + BJ - 1) / BJ), (unsigned)nsplit);
-#define LNRF_BIG(BF, AR, BR)                                                                                       \
-  hipLaunchKernelGGL((gemm_big_kernel<BF, AR, BR>), grid, dim3(256), 0, stream, a, lda, b, ldb, c, ldc, bias, act, \
-                     mode, I, J, R, per, gate)
+#define LNRF_BIG(BF, AR, BR)                                                                                          \
+  do {                                                                                                                \
+    if (b_al)                                                                                                         \
+      hipLaunchKernelGGL((gemm_big_kernel<BF, AR, BR, true>), grid, dim3(256), 0, stream, a, lda, b, ldb, c, ldc, bias, \
+                         act, mode, I, J, R, per, gate);                                                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL((gemm_big_kernel<BF, AR, BR, false>), grid, dim3(256), 0, stream, a, lda, b, ldb, c, ldc,    \
+                         bias, act, mode, I, J, R, per, gate);                                                        \
+  } while (0)
     const bool ar = a_fast_r, br = !b_fast_j;
     if (g_dense_bf16) {
       if (ar && br) LNRF_BIG(true, true, true); else if (ar) LNRF_BIG(true, true, false);
