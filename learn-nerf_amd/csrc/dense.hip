@@ -193,8 +193,25 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int64_t i0 = (int64_t)blockIdx.x * BI;
-  const int j0 = blockIdx.y * BJ;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so
+  // the column tiles of one row tile are placed 8 blocks apart: the second one finds the A tile in its XCD's L2
+  // instead of re-reading it from HBM.  blockIdx.x = (8 nj) g + 8 jt + t  ->  row tile 8 g + t, column tile jt.
+  // (Few row tiles, e.g. the split-K weight gradient: plain order, or all the work would land on ni of the 8 XCDs.)
+  const int nj = (J + BJ - 1) / BJ;
+  const int64_t ni = (I + BI - 1) / BI;
+  int64_t it;
+  int jt;
+  if (ni >= 64) {
+    const unsigned grp = blockIdx.x / (8u * nj), rem = blockIdx.x % (8u * nj);
+    it = (int64_t)grp * 8 + (rem & 7u);
+    jt = (int)(rem >> 3);
+  } else {
+    it = blockIdx.x % (unsigned)ni;
+    jt = (int)(blockIdx.x / (unsigned)ni);
+  }
+  const int64_t i0 = it * BI;
+  if (i0 >= I || jt >= nj) return;
+  const int j0 = jt * BJ;
   const int64_t r_begin = (int64_t)blockIdx.z * r_per_split;
   const int64_t r_end = r_begin + r_per_split < R ? r_begin + r_per_split : R;
 
@@ -456,7 +473,8 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
     if (per % 4 != 0) per = ((per + 3) / 4) * 4;
     int nsplit = (int)((R + per - 1) / per);
     if (nsplit < 1) nsplit = 1;
-    dim3 grid((unsigned)((I + BI - 1) / BI), (unsigned)((J + BJ - 1) / BJ), (unsigned)nsplit);
+    const int64_t ni = (I + BI - 1) / BI, njt = (J + BJ - 1) / BJ;
+    dim3 grid((unsigned)((ni >= 64 ? ((ni + 7) / 8) * 8 : ni) * njt), 1u, (unsigned)nsplit);  // tile order: see the kernel
 #define LNRF_BIG(BF, AR, BR)                                                                                          \
   do {                                                                                                                \
     if (b_al)                                                                                                         \
