@@ -192,3 +192,31 @@ def test_dense_precision_switch_is_scoped():
         with ops.dense_precision("fp16"):
             pass
     assert lib.lnrf_set_dense_precision(7) < 0 and b"precision" in lib.lnrf_last_error()
+
+
+def test_ref_nerf_train_step_bf16_tracks_fp32():
+    """One TrainLoop step of RefNERFModel with bf16 dense operands stays next to the exact-fp32 step (same rays,
+    same Philox noise): losses within 2e-3, gradient cosine > 0.999."""
+    from learn_nerf.ref_nerf import RefNERFModel
+    from learn_nerf.rng import Key
+    from learn_nerf.train import TrainLoop
+
+    kw = dict(hidden_dim=64, color_layer_dim=32, sh_degree=3)
+    n = 192
+    gen = torch.Generator().manual_seed(3)
+    o = torch.randn(n, 3, generator=gen)
+    o = 4 * o / o.norm(dim=-1, keepdim=True)
+    d = -o + (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+    d = d / d.norm(dim=-1, keepdim=True)
+    batch = torch.stack([o, d, torch.rand(n, 3, generator=gen) * 2 - 1], 1).float().contiguous().cuda()
+    logs, grads = {}, {}
+    for precision in ("fp32", "bf16"):
+        loop = TrainLoop(RefNERFModel(precision=precision, **kw), RefNERFModel(precision=precision, **kw), init_rng=8,
+                         lr=1e-3, coarse_ts=16, fine_ts=32)
+        logs[precision] = {k: float(v) for k, v in loop.step_fn((-1.0,) * 3, (1.0,) * 3)(Key(5), batch).items()}
+        grads[precision] = loop.grad.clone()
+    for k in ("coarse", "fine", "coarse_normal_mse", "fine_normal_mse", "fine_neg_normal"):
+        assert abs(logs["bf16"][k] - logs["fp32"][k]) < 2e-3 * (1 + abs(logs["fp32"][k])), (k, logs)
+    cos = torch.nn.functional.cosine_similarity(grads["bf16"], grads["fp32"], dim=0).item()
+    print(f"ref-nerf train step bf16 vs fp32: fine {logs['bf16']['fine']:.6f}/{logs['fp32']['fine']:.6f}, grad cosine {cos:.6f}")
+    assert cos > 0.999
