@@ -460,10 +460,9 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
   const bool a_fast_r = sa_r == 1, a_fast_i = sa_i == 1 && !a_fast_r;
   const bool b_fast_r = sb_r == 1, b_fast_j = sb_j == 1;
   const int64_t lda = a_fast_r ? sa_i : sa_r, ldb = b_fast_r ? sb_j : sb_r;
-  // A contiguous in i (X^T of the weight gradient) only with bf16 operands, where the swizzled LDS image keeps the
-  // transposing stores nearly conflict-free; in f32 the generic kernel is as fast
+  // A contiguous in i = X^T of the weight gradient: transposing LDS stores (swizzled bf16 image / 17-float rows in f32)
   const bool b_al = aligned16(b);  // weights inside a flat parameter vector may start at any float
-  const bool big = (a_fast_r || (a_fast_i && g_dense_bf16)) && (b_fast_r || b_fast_j) && aligned16(a) &&
+  const bool big = (a_fast_r || a_fast_i) && (b_fast_r || b_fast_j) && aligned16(a) &&
                    lda % 4 == 0 && ldb % 4 == 0 && (a_fast_r ? R % 4 == 0 : I % 4 == 0) &&
                    (b_fast_r ? R % 4 == 0 : J % 4 == 0) && I >= 64 && J >= 64 && R >= 32;
   if (big) {
@@ -489,7 +488,8 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
       if (ar && br) LNRF_BIG(true, true, true); else if (ar) LNRF_BIG(true, true, false);
       else if (br) LNRF_BIG(true, false, true); else LNRF_BIG(true, false, false);
     } else {
-      if (br) LNRF_BIG(false, true, true); else LNRF_BIG(false, true, false);
+      if (ar && br) LNRF_BIG(false, true, true); else if (ar) LNRF_BIG(false, true, false);
+      else if (br) LNRF_BIG(false, false, true); else LNRF_BIG(false, false, false);
     }
 #undef LNRF_BIG
     hipError_t e = hipGetLastError();
