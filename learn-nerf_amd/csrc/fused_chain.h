@@ -37,6 +37,26 @@ constexpr int kFragAhead = 4;        // A-fragments read from LDS ahead of the M
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
+// In-kernel timeline (debug builds with -DLNRF_TIMELINE only, see tools/timeline_probe.py): the waves of one
+// workgroup write s_memtime stamps to a buffer; compiled out of the product library.
+#ifdef LNRF_TIMELINE
+struct Timeline {
+  unsigned long long* buf = nullptr;  // [8 waves][1024 stamps]
+  int n = 0;
+  bool on = false;
+  __device__ __forceinline__ void stamp() {
+    if (on) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) buf[(threadIdx.x >> 6) * 1024 + n] = t;
+      ++n;
+    }
+  }
+};
+#define LNRF_TL_STAMP(ring) (ring).tl.stamp()
+#else
+#define LNRF_TL_STAMP(ring) ((void)0)
+#endif
+
 __device__ __forceinline__ bf16x8 bits_to_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ uint4 frag_to_bits(bf16x8 v) { return __builtin_bit_cast(uint4, v); }
 __device__ __forceinline__ bf16x8 zero_frag() { return bits_to_frag(make_uint4(0, 0, 0, 0)); }
@@ -55,6 +75,9 @@ struct Ring {
   int wave, lane;
   uint4 r[2][2];
   bf16x8 fifo[kFragAhead];
+#ifdef LNRF_TIMELINE
+  Timeline tl;
+#endif
 
   template <int T>
   __device__ __forceinline__ void load() {
@@ -97,7 +120,13 @@ struct Ring {
   // barrier that opens stage T (T >= 1): frees the slot of stage T-1, publishes stage T+1
   template <int T>
   __device__ __forceinline__ void advance() {
+#ifdef LNRF_TIMELINE
+    tl.stamp();  // arrived at the stage barrier
+#endif
     __syncthreads();
+#ifdef LNRF_TIMELINE
+    tl.stamp();  // released
+#endif
     if constexpr (T + 2 < NSTAGES) write<T + 2>();
     if constexpr (T + 4 < NSTAGES) load<T + 4>();
   }
@@ -202,7 +231,9 @@ __device__ __forceinline__ void chain_layer(RING& ring, Init init, GetB getb, Ep
       // per step does it; sched_group_barrier gives the same code but costs ~15 min of compile time here.
       __builtin_amdgcn_sched_barrier(0);
     });
+    LNRF_TL_STAMP(ring);  // MFMAs of the tile issued
     epi(o_, acc);
+    LNRF_TL_STAMP(ring);  // epilogue issued
   });
 }
 

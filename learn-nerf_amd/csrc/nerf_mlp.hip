@@ -74,7 +74,14 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   ring.stream = packed + kPackFwdOff;
   ring.wave = wave;
   ring.lane = lane;
+#ifdef LNRF_TIMELINE
+  ring.tl.buf = reinterpret_cast<unsigned long long*>(save);  // debug build: `save` of the no-save kernel = stamp buffer
+  ring.tl.n = 0;
+  ring.tl.on = !SAVE && save != nullptr && blockIdx.x == gridDim.x / 2;
+  ring.tl.stamp();
+#endif
   ring.prologue();
+  LNRF_TL_STAMP(ring);
 
   // positional encodings (model.py:65-77) in fp32, rounded to bf16 operands
   bf16x8 xe[4], de[2];
@@ -512,7 +519,12 @@ extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packe
     hipLaunchKernelGGL((nerf_fwd_kernel<SAVE, RAYS>), grid, block, kFusedLds, st, (const char*)packed, \
                        x, d, rays, ray_stride, ts, (int)t, m, n_tiles, density, rgb, (char*)save);   \
   } while (0)
-  if (save) {
+#ifdef LNRF_TIMELINE
+  const bool use_save_kernel = false;  // debug build: `save` carries the stamp buffer of the no-save kernel
+#else
+  const bool use_save_kernel = save != nullptr;
+#endif
+  if (use_save_kernel) {
     if (from_rays) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false);
   } else {
     if (from_rays) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false);
