@@ -14,6 +14,9 @@
 namespace lnrf {
 
 constexpr int kFusedLds = kRingBytes + round_up(kBiasFloats * 4, 1024);
+#ifdef LNRF_TIMELINE
+__device__ unsigned long long* g_timeline_buf = nullptr;  // 3 kernels x 8 waves x 1024 stamps (debug build only)
+#endif
 
 struct FwdSeq {
   static constexpr int count = kFwdUsed;
@@ -41,7 +44,6 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t m = tile * kTileCols + c;
   const bool valid = m < M;
-  const bool tile_ok = tile < n_tiles;
 
   // biases -> LDS, inputs -> registers (all ordinary loads retire before the first LDS-DMA)
   {
@@ -75,9 +77,9 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
   ring.wave = wave;
   ring.lane = lane;
 #ifdef LNRF_TIMELINE
-  ring.tl.buf = reinterpret_cast<unsigned long long*>(save);  // debug build: `save` of the no-save kernel = stamp buffer
+  ring.tl.buf = g_timeline_buf + (SAVE ? 0 : 8 * 1024);  // [save fwd | inference fwd | chain] x 8 waves x 1024 stamps
   ring.tl.n = 0;
-  ring.tl.on = !SAVE && save != nullptr && blockIdx.x == gridDim.x / 2;
+  ring.tl.on = g_timeline_buf != nullptr && blockIdx.x == gridDim.x / 2;
   ring.tl.stamp();
 #endif
   ring.prologue();
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 
   DumpAddr dump{save, n_tiles, tile, c, h};
   auto save_frag = [&](int slot, const bf16x8& f) {
-    if (SAVE && tile_ok) stream_store(dump.at(slot), frag_to_bits(f));
+    if (SAVE) stream_store(dump.at(slot), frag_to_bits(f));
   };
   if (SAVE) {
     static_for<4>([&](auto i) { save_frag(kSaveXin + decltype(i)::value, xe[decltype(i)::value]); });
@@ -151,9 +153,8 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           if constexpr (SAVE && RELU) mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
         });
     if constexpr (SAVE && RELU) {
-      if (tile_ok)
-        *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile) * kFragBytes + lane * 16) =
-            make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
+      *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile) * kFragBytes + lane * 16) =
+          make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
       mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
     }
   };
@@ -187,9 +188,8 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           if constexpr (SAVE) mask_bits[o >> 1] |= relu_bits(a1[2 * o], a1[2 * o + 1]) << (16 * (o & 1));
         } else {
           if constexpr (SAVE) {
-            if (tile_ok)
-              *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + 8) * n_tiles + tile) * kFragBytes +
-                                        lane * 16) = make_uint4(mask_bits[0], mask_bits[1], 0u, 0u);
+            *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + 8) * n_tiles + tile) * kFragBytes +
+                                      lane * 16) = make_uint4(mask_bits[0], mask_bits[1], 0u, 0u);
           }
           if (h == 0 && valid) {
             const float x = acc[0];
@@ -226,7 +226,6 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t m = tile * kTileCols + c;
   const bool valid = m < M;
-  const bool tile_ok = tile < n_tiles;
 
   // head gradients (fp32): d/d(pre-tanh) and d/d(density logit)
   float gy11[3] = {0, 0, 0}, gy9 = 0.0f;
@@ -242,20 +241,26 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   uint4 relu_mask[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
-    relu_mask[i] = tile_ok ? *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) *
-                                                                        kFragBytes + lane * 16)
-                           : make_uint4(0, 0, 0, 0);
+    relu_mask[i] = *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) * kFragBytes +
+                                                   lane * 16);
   __syncthreads();
 
   Ring<kBwdStages, BwdSeq> ring;
   ring.stream = packed + kPackBwdOff;
   ring.wave = wave;
   ring.lane = lane;
+#ifdef LNRF_TIMELINE
+  ring.tl.buf = g_timeline_buf + 16 * 1024;
+  ring.tl.n = 0;
+  ring.tl.on = g_timeline_buf != nullptr && blockIdx.x == gridDim.x / 2;
+  ring.tl.stamp();
+#endif
   ring.prologue();
+  LNRF_TL_STAMP(ring);
 
   DumpAddr gd{gdump, n_tiles, tile, c, h};
   auto dump_frag = [&](int slot, const bf16x8& f) {
-    if (tile_ok) stream_store(gd.at(slot), frag_to_bits(f));
+    stream_store(gd.at(slot), frag_to_bits(f));
   };
 
   bf16x8 a0[16], a1[16];
@@ -450,7 +455,10 @@ static bool shape_supported(const lnrf_nerf_shape* s) {
   return s && s->input_layers == 5 && s->mid_layers == 4 && s->hidden_dim == 256 &&
          s->color_layer_dim == 128 && s->x_freqs == 10 && s->d_freqs == 4;
 }
-static inline int64_t tiles_for(int64_t m) { return (m + kTileCols - 1) / kTileCols; }
+// Tiles are padded to whole workgroups (8 waves): every wave then owns a dump slot, so the dump stores need no
+// branch — a conditional store makes hipcc lose count of the outstanding VMEM operations and wait vmcnt(0) (= drain all
+// dump stores) before every ring write.  Padding tiles hold finite activations and zero gradients.
+static inline int64_t tiles_for(int64_t m) { return ((m + kTileCols - 1) / kTileCols + kWaves - 1) / kWaves * kWaves; }
 
 extern "C" int64_t lnrf_nerf_param_count(const lnrf_nerf_shape* s) {
   if (!s) return -1;
@@ -519,11 +527,7 @@ extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packe
     hipLaunchKernelGGL((nerf_fwd_kernel<SAVE, RAYS>), grid, block, kFusedLds, st, (const char*)packed, \
                        x, d, rays, ray_stride, ts, (int)t, m, n_tiles, density, rgb, (char*)save);   \
   } while (0)
-#ifdef LNRF_TIMELINE
-  const bool use_save_kernel = false;  // debug build: `save` carries the stamp buffer of the no-save kernel
-#else
   const bool use_save_kernel = save != nullptr;
-#endif
   if (use_save_kernel) {
     if (from_rays) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false);
   } else {
@@ -612,3 +616,11 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
+
+#ifdef LNRF_TIMELINE
+// debug library only (tools/build_timeline.sh): where the stamped workgroup writes its s_memtime values
+extern "C" int lnrf_debug_set_timeline(void* buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(lnrf::g_timeline_buf), &buf, sizeof(buf));
+  return e == hipSuccess ? LNRF_OK : hip_fail(e, "hipMemcpyToSymbol(g_timeline_buf)");
+}
+#endif
