@@ -81,7 +81,6 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
   const int64_t m = tile * kTileCols + c;
   const bool valid = m < M;
-  const bool tile_ok = tile < n_tiles;
 
   {
     const float* bias_g = reinterpret_cast<const float*>(packed + kNgpPackBiasOff);
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
 
   DumpAddr dump{scratch, n_tiles, tile, c, h};
   auto dump_frag = [&](int slot, const bf16x8& f) {
-    if (BWD && tile_ok) stream_store(dump.at(slot), frag_to_bits(f));
+    if (BWD) stream_store(dump.at(slot), frag_to_bits(f));  // unconditional: tiles are padded to whole workgroups
   };
 
   bf16x8 h0[4], o16, c1[4], c2[4];
@@ -395,7 +394,8 @@ static bool ngp_supported(const lnrf_ngp_mlp_desc* d) {
   return d && d->hidden_dim == kNgpHidden && d->density_dim == kNgpDensityDim && d->density_layers == 1 &&
          d->color_layers == 2 && d->d_freqs == 4 && d->enc_dim >= 1 && d->enc_dim <= 32;
 }
-static inline int64_t ngp_tiles(int64_t m) { return (m + kTileCols - 1) / kTileCols; }
+// padded to whole workgroups (8 waves) so that the dump stores need no branch (see tiles_for in nerf_mlp.hip)
+static inline int64_t ngp_tiles(int64_t m) { return ((m + kTileCols - 1) / kTileCols + kWaves - 1) / kWaves * kWaves; }
 static NgpOffsets ngp_offsets(const lnrf_ngp_mlp_desc* d) {
   NgpOffsets o;
   int64_t off = d->dense_offset;
