@@ -299,6 +299,19 @@ int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packed, const fl
                       int32_t t, int64_t m, float* density, float* rgb, void* save,
                       lnrf_stream_t stream);
 
+/* Split-precision ("bf16x3") evaluation of NeRFModel.__call__ (model.py:43-62), the render / evaluation path:
+ * the reference computes this in fp32 (model.py:72, render.py:140); here every fp32 operand is carried as
+ * a bf16 pair hi + lo and every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
+ * (16 significant bits per operand; rendered RGB within 1e-3 of the fp32 reference, tests/test_gpu_nerf_mlp.py).
+ * lnrf_nerf_packed_split_bytes: size of the opaque [hi,lo] fragment stream made by lnrf_nerf_pack_weights_split.
+ * lnrf_nerf_mlp_fwd_split: same arguments as lnrf_nerf_mlp_fwd without the save buffer (inference only). */
+int64_t lnrf_nerf_packed_split_bytes(const lnrf_nerf_shape* shape);
+int lnrf_nerf_pack_weights_split(const lnrf_nerf_shape* shape, const float* params, void* packed_split,
+                                 lnrf_stream_t stream);
+int lnrf_nerf_mlp_fwd_split(const lnrf_nerf_shape* shape, const void* packed_split, const float* x,
+                            const float* d, const float* rays, int64_t ray_stride, const float* ts,
+                            int32_t t, int64_t m, float* density, float* rgb, lnrf_stream_t stream);
+
 /* Backward of the above wrt the parameters: grads[param_count] += d L / d params given
  * g_density[M], g_rgb[M,3] (= d L / d outputs), the forward outputs and the save buffer.
  * Equals lnrf_nerf_mlp_bwd_chain followed by lnrf_nerf_mlp_bwd_weights. */

@@ -32,7 +32,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 __device__ __forceinline__ float act_grad_from_output(float y, int act) {
   switch (act) {
     case LNRF_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
-    case LNRF_ACT_SOFTPLUS: return 1.0f - expf(-y);  // sigmoid(x) = 1 - exp(-softplus(x))
+    case LNRF_ACT_SOFTPLUS: return -expm1f(-y);  // sigmoid(x) = 1 - exp(-softplus(x)), no cancellation
     case LNRF_ACT_TANH: return 1.0f - y * y;
     case LNRF_ACT_EXP: return y;
     case LNRF_ACT_SIGMOID: return y * (1.0f - y);

@@ -69,11 +69,12 @@ __device__ __forceinline__ bf16x8 zero_frag() { return bits_to_frag(make_uint4(0
 // T+2 is written from registers into the slot freed by stage T-1, stage T+4 is requested from L2.
 // Because stage T+1 is visible during stage T, the per-wave FIFO of A-fragments (kFragAhead LDS reads
 // in flight) runs continuously across stage boundaries.
-template <int NSTAGES, class SEQ>
+template <int NSTAGES, class SEQ, int NW = kWaves>
 struct Ring {
+  static constexpr int kPerWave = kStageFrags / NW;  // fragments of a stage moved by one wave
   const char* stream;  // global, NSTAGES * 16 KiB, fragment order
   int wave, lane;
-  uint4 r[2][2];
+  uint4 r[2][kPerWave];
   bf16x8 fifo[kFragAhead];
 #ifdef LNRF_TIMELINE
   Timeline tl;
@@ -82,8 +83,8 @@ struct Ring {
   template <int T>
   __device__ __forceinline__ void load() {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = wave + kWaves * q;
+    for (int q = 0; q < kPerWave; ++q) {
+      const int f = wave + NW * q;
       r[T & 1][q] = *reinterpret_cast<const uint4*>(stream + ((int64_t)T * kStageFrags + f) * kFragBytes +
                                                     lane * 16);
     }
@@ -91,8 +92,8 @@ struct Ring {
   template <int T>
   __device__ __forceinline__ void write() {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int f = wave + kWaves * q;
+    for (int q = 0; q < kPerWave; ++q) {
+      const int f = wave + NW * q;
       *reinterpret_cast<uint4*>(&smem[(T % kSlots) * kStageBytes + f * kFragBytes + lane * 16]) = r[T & 1][q];
     }
   }

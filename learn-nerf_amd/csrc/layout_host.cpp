@@ -14,6 +14,10 @@ int lnrf_host_bwd_frags(void) { return kBwdFrags; }
 int lnrf_host_bias_floats(void) { return kBiasFloats; }
 int lnrf_host_fwd_used(void) { return kFwdUsed; }
 int lnrf_host_fwd_seq(int c) { return fwd_seq(c); }
+int lnrf_host_fwd3_frags(void) { return kFwd3Frags; }
+int lnrf_host_fwd3_used(void) { return kFwd3Used; }
+int lnrf_host_fwd3_seq(int c) { return fwd3_seq(c); }
+int lnrf_host_fwd3_base(int s) { return fwd3_base(s); }
 int lnrf_host_bwd_seq(int c) { return bwd_seq(c); }
 int lnrf_host_fwd_layer_info(int s, int what) {
   return what == 0 ? fwd_nk(s) : what == 1 ? fwd_no(s) : what == 2 ? fwd_base(s) : what == 3 ? fwd_bias_base(s)

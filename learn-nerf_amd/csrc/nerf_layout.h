@@ -151,6 +151,27 @@ NL_HD constexpr int fwd_bias_index(int s, int row) {
   return row < 3 ? dense_b_off(11) + row : -1;
 }
 
+// ---- split-precision forward weight stream ("bf16x3") ------------------------------------------
+// Every fp32 weight w is carried as two bf16 values hi = bf16(w), lo = bf16(w - hi); the stream holds, for
+// each (layer, out-tile, k-step) of the forward stream above, the pair [hi frag, lo frag].  The render kernel
+// forms hi*hi + hi*lo + lo*hi per product with fp32 accumulation (the dropped lo*lo term is ~2^-16 relative).
+NL_HD constexpr int fwd3_base(int s) {
+  int b = 0;
+  for (int i = 0; i < s; ++i) b += round_up(2 * fwd_nk(i) * fwd_no(i), kStageFrags);
+  return b;
+}
+constexpr int kFwd3Frags = fwd3_base(kFwdLayers);  // 2384
+static_assert(kFwd3Frags == 2384, "split forward stream length");
+constexpr int kFwd3Used = 2 * kFwdUsed;
+NL_HD constexpr int fwd3_seq(int c) {  // c-th consumed fragment (2 per MFMA k-step: hi, lo) -> stream index
+  int s = 0;
+  for (int i = 1; i < kFwdLayers; ++i)
+    if (c >= 2 * fwd_cons_base(i)) s = i;
+  return fwd3_base(s) + (c - 2 * fwd_cons_base(s));
+}
+constexpr int64_t kPack3BiasOff = (int64_t)kFwd3Frags * kFragBytes;
+constexpr int64_t kPack3Bytes = kPack3BiasOff + round_up(kBiasFloats * 4, 1024);
+
 // ---- backward (input-gradient) weight stream --------------------------------------------------
 // stream layers t: 0 = Dense_11^T, 1 = L10m^T (z rows only), 2..4 = Dense_8..6^T,
 // 5 = Dense_5^T (h rows only), 6..9 = Dense_4..1^T.   A rows = layer inputs, k = layer outputs.

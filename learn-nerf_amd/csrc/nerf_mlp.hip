@@ -211,6 +211,213 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-precision forward ("bf16x3", render / evaluation path; model.py:43-62 is fp32 in the reference).
+// Same chain as nerf_fwd_kernel<false>, but every operand is a bf16 pair (hi, lo) with hi + lo equal to the
+// fp32 value to 16 significant bits, and every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32
+// accumulation.  The activations of a layer therefore need 2 x 64 VGPRs in and 2 x 64 out: the workgroup is
+// 4 waves (one per SIMD) so that each wave may use the whole 512-entry register file.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSplitWaves = 4;
+constexpr int kSplitThreads = kSplitWaves * 64;
+constexpr int kFwd3Stages = kFwd3Frags / kStageFrags;  // 149
+struct Fwd3Seq {
+  static constexpr int count = kFwd3Used;
+  static constexpr int at(int c) { return fwd3_seq(c); }
+};
+
+// v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
+template <int S, bool RELU>
+__device__ __forceinline__ void acc_to_frag_split(const f32x16& acc, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc[8 * S + j];
+    if (RELU) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
+    const __bf16 hb = (__bf16)v;
+    hi[j] = hb;
+    lo[j] = (__bf16)(v - (float)hb);
+  }
+}
+__device__ __forceinline__ void split_store(float v, bf16x8& hi, bf16x8& lo, int j) {
+  const __bf16 hb = (__bf16)v;
+  hi[j] = hb;
+  lo[j] = (__bf16)(v - (float)hb);
+}
+
+// one GEMM layer with split operands; C0 = consumption index (in hi/lo pairs) of the layer's first k-step
+template <int C0, int NK, int NO, class RING, class Init, class GetHi, class GetLo, class Epi>
+__device__ __forceinline__ void chain_layer_split(RING& ring, Init init, GetHi bhi, GetLo blo, Epi epi) {
+  static_for<NO>([&](auto o_) {
+    constexpr int o = decltype(o_)::value;
+    f32x16 acc = init(o_);
+    static_for<NK>([&](auto k_) {
+      constexpr int ks = decltype(k_)::value;
+      constexpr int c = 2 * (C0 + o * NK + ks);
+      const bf16x8 ahi = ring.template next<c>();
+      const bf16x8 alo = ring.template next<c + 1>();
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi(k_), acc, 0, 0, 0);  // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo(k_), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi(k_), acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    epi(o_, acc);
+  });
+}
+
+template <bool FROM_RAYS>
+__global__ __launch_bounds__(kSplitThreads) void nerf_fwd_split_kernel(
+    const char* __restrict__ packed, const float* __restrict__ xin_g, const float* __restrict__ din_g,
+    const float* __restrict__ rays, int64_t ray_stride, const float* __restrict__ ts, int T, int64_t M,
+    float* __restrict__ density, float* __restrict__ rgb) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kSplitWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+
+  {
+    const float* bias_g = reinterpret_cast<const float*>(packed + kPack3BiasOff);
+    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
+    for (int i = tid; i < kBiasFloats; i += kSplitThreads) bias_l[i] = bias_g[i];
+  }
+  float px[3] = {0, 0, 0}, pd[3] = {0, 0, 0};
+  if (valid) {
+    if (FROM_RAYS) {
+      const int64_t n = m / T;
+      const float t = ts[m];
+      const float* r = rays + n * ray_stride;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        pd[a] = r[3 + a];
+        px[a] = r[a] + pd[a] * t;  // render.py:153
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        px[a] = xin_g[m * 3 + a];
+        pd[a] = din_g[m * 3 + a];
+      }
+    }
+  }
+  __syncthreads();
+
+  Ring<kFwd3Stages, Fwd3Seq, kSplitWaves> ring;
+  ring.stream = packed;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+
+  // positional encodings (model.py:65-77) in fp32, split into bf16 pairs
+  bf16x8 xe_hi[4], xe_lo[4], de_hi[2], de_lo[2];
+  static_for<4>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int p = 4 * ks + pp;
+      float s = 0.0f, co = 0.0f;
+      if (p < 15) {
+        const int pg = 15 * h + p;
+        const int cd = pg / 10, f = pg - 10 * cd;
+        const float v = cd == 0 ? px[0] : (cd == 1 ? px[1] : px[2]);
+        sincos_pe(v * (float)(1 << f), &s, &co);
+      }
+      split_store(s, xe_hi[ks], xe_lo[ks], 2 * pp);
+      split_store(co, xe_hi[ks], xe_lo[ks], 2 * pp + 1);
+    }
+  });
+  static_for<2>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int p = 4 * ks + pp;
+      float s = 0.0f, co = 0.0f;
+      if (p < 6) {
+        const int pg = 6 * h + p;
+        const int cd = pg >> 2, f = pg & 3;
+        const float v = cd == 0 ? pd[0] : (cd == 1 ? pd[1] : pd[2]);
+        sincos_pe(v * (float)(1 << f), &s, &co);
+      }
+      split_store(s, de_hi[ks], de_lo[ks], 2 * pp);
+      split_store(co, de_hi[ks], de_lo[ks], 2 * pp + 1);
+    }
+  });
+
+  bf16x8 a0h[16], a0l[16], a1h[16], a1l[16];
+
+  auto hidden = [&](auto s_, bf16x8(&inh)[16], bf16x8(&inl)[16], bf16x8(&outh)[16], bf16x8(&outl)[16], auto relu_) {
+    constexpr int S = decltype(s_)::value;
+    constexpr bool RELU = decltype(relu_)::value;
+    chain_layer_split<fwd_cons_base(S), fwd_nk(S), fwd_no(S)>(
+        ring, [&](auto o_) { return bias_acc(fwd_bias_base(S) + 32 * decltype(o_)::value, h); },
+        [&](auto k_) -> bf16x8 {
+          constexpr int ks = decltype(k_)::value;
+          if constexpr (S == 0) return xe_hi[ks];
+          else if constexpr (ks < 16) return inh[ks];
+          else return xe_hi[ks - 16];
+        },
+        [&](auto k_) -> bf16x8 {
+          constexpr int ks = decltype(k_)::value;
+          if constexpr (S == 0) return xe_lo[ks];
+          else if constexpr (ks < 16) return inl[ks];
+          else return xe_lo[ks - 16];
+        },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          acc_to_frag_split<0, RELU>(acc, outh[2 * o], outl[2 * o]);
+          acc_to_frag_split<1, RELU>(acc, outh[2 * o + 1], outl[2 * o + 1]);
+        });
+  };
+  std::true_type relu;
+  std::false_type lin;
+  hidden(std::integral_constant<int, 0>{}, a1h, a1l, a0h, a0l, relu);
+  hidden(std::integral_constant<int, 1>{}, a0h, a0l, a1h, a1l, relu);
+  hidden(std::integral_constant<int, 2>{}, a1h, a1l, a0h, a0l, relu);
+  hidden(std::integral_constant<int, 3>{}, a0h, a0l, a1h, a1l, relu);
+  hidden(std::integral_constant<int, 4>{}, a1h, a1l, a0h, a0l, relu);
+  hidden(std::integral_constant<int, 5>{}, a0h, a0l, a1h, a1l, relu);
+  hidden(std::integral_constant<int, 6>{}, a1h, a1l, a0h, a0l, relu);
+  hidden(std::integral_constant<int, 7>{}, a0h, a0l, a1h, a1l, relu);
+  hidden(std::integral_constant<int, 8>{}, a1h, a1l, a0h, a0l, lin);
+
+  chain_layer_split<fwd_cons_base(9), fwd_nk(9), fwd_no(9)>(
+      ring, [&](auto o_) { return bias_acc(fwd_bias_base(9) + 32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 {
+        constexpr int ks = decltype(k_)::value;
+        if constexpr (ks < 16) return a0h[ks];
+        else return de_hi[ks - 16];
+      },
+      [&](auto k_) -> bf16x8 {
+        constexpr int ks = decltype(k_)::value;
+        if constexpr (ks < 16) return a0l[ks];
+        else return de_lo[ks - 16];
+      },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        if constexpr (o < 4) {
+          acc_to_frag_split<0, true>(acc, a1h[2 * o], a1l[2 * o]);
+          acc_to_frag_split<1, true>(acc, a1h[2 * o + 1], a1l[2 * o + 1]);
+        } else {
+          if (h == 0 && valid) {
+            const float x = acc[0];
+            density[m] = fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));  // softplus (model.py:57)
+          }
+        }
+      });
+  chain_layer_split<fwd_cons_base(10), fwd_nk(10), fwd_no(10)>(
+      ring, [&](auto) { return bias_acc(fwd_bias_base(10), h); },
+      [&](auto k_) -> bf16x8 { return a1h[decltype(k_)::value]; },
+      [&](auto k_) -> bf16x8 { return a1l[decltype(k_)::value]; },
+      [&](auto, const f32x16& acc) {
+        if (h == 0 && valid) {
+          rgb[m * 3 + 0] = tanhf(acc[0]);
+          rgb[m * 3 + 1] = tanhf(acc[1]);
+          rgb[m * 3 + 2] = tanhf(acc[2]);
+        }
+      });
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward, part 1: input-gradient chain.  Produces dy_l (pre-activation gradients) dumps.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBwdStages = kBwdFrags / kStageFrags;  // 70
@@ -235,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
       const float y = rgb[m * 3 + k];
       gy11[k] = g_rgb[m * 3 + k] * (1.0f - y * y);             // tanh'
     }
-    gy9 = g_density[m] * (1.0f - expf(-density[m]));           // softplus' = sigmoid = 1 - exp(-sp)
+    gy9 = g_density[m] * -expm1f(-density[m]);                // softplus' = sigmoid = 1 - exp(-sp), no cancellation
   }
   // ReLU masks of h0..h7 and h10 (written by the forward), 16 bytes per lane and layer
   uint4 relu_mask[9];
@@ -447,6 +654,37 @@ __global__ void nerf_pack_kernel(const float* __restrict__ params, char* __restr
   }
 }
 
+// split stream: [hi frag, lo frag] per forward (layer, out-tile, k-step); fp32 bias block behind it
+__global__ void nerf_pack_split_kernel(const float* __restrict__ params, char* __restrict__ packed) {
+  const int64_t total_w = (int64_t)kFwd3Frags * 512;
+  const int64_t total = total_w + kBiasFloats;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < total_w) {
+      const int g = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
+      int s = 0;
+      for (int i = 1; i < kFwdLayers; ++i)
+        if (g >= fwd3_base(i)) s = i;
+      const int loc = g - fwd3_base(s);
+      int idx = -1;
+      if (loc < 2 * fwd_nk(s) * fwd_no(s)) {
+        const int pair = loc >> 1;
+        idx = fwd_weight_index(s, pair / fwd_nk(s), pair % fwd_nk(s), lane, j);
+      }
+      const float w = idx >= 0 ? params[idx] : 0.0f;
+      const __bf16 hi = (__bf16)w;
+      reinterpret_cast<__bf16*>(packed)[e] = (loc & 1) ? (__bf16)(w - (float)hi) : hi;
+    } else {
+      const int i = (int)(e - total_w);
+      int s = 0;
+      for (int k = 1; k < kFwdLayers; ++k)
+        if (i >= fwd_bias_base(k)) s = k;
+      const int idx = fwd_bias_index(s, i - fwd_bias_base(s));
+      reinterpret_cast<float*>(packed + kPack3BiasOff)[i] = idx >= 0 ? params[idx] : 0.0f;
+    }
+  }
+}
+
 }  // namespace lnrf
 
 using namespace lnrf;
@@ -534,6 +772,54 @@ extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packe
     if (from_rays) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false);
   }
 #undef LAUNCH_FWD
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int64_t lnrf_nerf_packed_split_bytes(const lnrf_nerf_shape* s) {
+  return shape_supported(s) ? kPack3Bytes : -1;
+}
+
+extern "C" int lnrf_nerf_pack_weights_split(const lnrf_nerf_shape* shape, const float* params, void* packed,
+                                            lnrf_stream_t stream) {
+  if (!shape_supported(shape)) {
+    set_error("lnrf_nerf_pack_weights_split: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
+    return LNRF_ERR_UNSUPPORTED;
+  }
+  LNRF_CHECK_ARG(params && packed, "null pointer");
+  hipLaunchKernelGGL(nerf_pack_split_kernel, dim3(1024), dim3(256), 0, as_stream(stream), params, (char*)packed);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_nerf_mlp_fwd_split(const lnrf_nerf_shape* shape, const void* packed_split, const float* x,
+                                       const float* d, const float* rays, int64_t ray_stride, const float* ts,
+                                       int32_t t, int64_t m, float* density, float* rgb, lnrf_stream_t stream) {
+  if (!shape_supported(shape)) {
+    set_error("lnrf_nerf_mlp_fwd_split: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
+    return LNRF_ERR_UNSUPPORTED;
+  }
+  LNRF_CHECK_ARG(packed_split && density && rgb, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  const bool from_rays = rays != nullptr;
+  if (from_rays) LNRF_CHECK_ARG(ts && t >= 1 && ray_stride >= 6 && m % t == 0, "rays mode needs ts, t, m = n*t");
+  else LNRF_CHECK_ARG(x && d, "need x and d (or rays and ts)");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = (m + kTileCols - 1) / kTileCols;
+  const dim3 grid((unsigned)((n_tiles + kSplitWaves - 1) / kSplitWaves)), block(kSplitThreads);
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (from_rays) {
+    rc = ensure_lds(nerf_fwd_split_kernel<true>, kFusedLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nerf_fwd_split_kernel<true>), grid, block, kFusedLds, st, (const char*)packed_split, x, d,
+                       rays, ray_stride, ts, (int)t, m, density, rgb);
+  } else {
+    rc = ensure_lds(nerf_fwd_split_kernel<false>, kFusedLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nerf_fwd_split_kernel<false>), grid, block, kFusedLds, st, (const char*)packed_split, x, d,
+                       rays, ray_stride, ts, (int)t, m, density, rgb);
+  }
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }

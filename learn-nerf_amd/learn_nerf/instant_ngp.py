@@ -11,6 +11,7 @@ from dataclasses import dataclass, field
 from typing import Any, Dict, List, Sequence, Tuple
 
 import ctypes
+from collections import OrderedDict
 
 import torch
 
@@ -133,17 +134,24 @@ class InstantNGPModel(ModelBase):
                             self.encoding().num_table_floats())
 
     def packed_weights(self, flat: torch.Tensor) -> torch.Tensor:
-        """bf16 MFMA-fragment copy of the Dense parameters; rebuilt when the flat buffer changes."""
-        key = (flat.data_ptr(), flat._version, flat.device, self._pack_generation)
-        if self._pack_cache is not None and self._pack_cache[0] == key:
-            return self._pack_cache[1]
+        """bf16 MFMA-fragment copy of the Dense parameters; rebuilt when the flat buffer changes.  As in
+        NeRFModel.packed_weights: a miss packs into a fresh buffer (a saved backward context may hold the old
+        one) and cache entries keep their source tensor alive so that a recycled address cannot hit."""
+        if self._pack_cache is None:
+            self._pack_cache = OrderedDict()
+        key = (flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
+        hit = self._pack_cache.get(key)
+        if hit is not None:
+            self._pack_cache.move_to_end(key)
+            return hit[1]
         desc = self._mlp_desc()
         nbytes = L.lib().lnrf_ngp_mlp_packed_bytes(ctypes.byref(desc))
-        packed = (self._pack_cache[1] if self._pack_cache is not None and self._pack_cache[1].device == flat.device
-                  else torch.empty(nbytes, dtype=torch.uint8, device=flat.device))
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
         L.check(L.lib().lnrf_ngp_mlp_pack(ctypes.byref(desc), L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
                 "ngp_mlp_pack")
-        self._pack_cache = (key, packed)
+        self._pack_cache[key] = (flat, packed)
+        while len(self._pack_cache) > 4:
+            self._pack_cache.popitem(last=False)
         return packed
 
     def _fused_forward_points(self, flat, x, d, save: bool):

@@ -5,10 +5,16 @@ Same constructor fields and call pattern as the Flax modules:
     params = model.init(dict(params=rng), x, d)["params"]
     density, rgb, aux = model.apply(dict(params=params), x, d)          (render.py:320-324)
 Arrays are torch tensors on the GPU.  NeRFModel has two compute paths, both hand-written HIP:
-  precision="bf16": fused bf16-MFMA kernels (nerf_mlp.hip) — the performance path;
+  precision="bf16": fused bf16-MFMA kernels (nerf_mlp.hip) — the performance path.  Training (forward with
+      saved activations + backward) runs on plain bf16 operands; every forward WITHOUT a backward (rendering,
+      evaluation, model.apply) runs the split-precision kernel (render_precision="bf16x3": bf16 hi+lo pairs,
+      three MFMAs per product, fp32 accumulate), which reproduces the reference's fp32 arithmetic
+      (model.py:72, render.py:140) to ~1e-5 so that rendered RGB meets the 1e-3 parity gate;
   precision="fp32": exact-fp32 dense kernels on the f32 MFMA (dense.hip) — parity/any shape.
 """
 import ctypes
+import warnings
+from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -109,10 +115,20 @@ class NeRFModel(ModelBase):
     x_freqs: int = 10
     d_freqs: int = 4
     precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
+    render_precision: str = "bf16x3"  # fused path, forward without backward: "bf16x3" (split) | "bf16"
     tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
 
     _pack_cache: Any = field(default=None, repr=False, compare=False)
     _pack_generation: int = field(default=0, repr=False, compare=False)
+    _warned_dense: bool = field(default=False, repr=False, compare=False)
+
+    def __post_init__(self):
+        # model.py:50-56 builds Dense_0..(input_layers-1) and the mid block; the reference's widths for an empty
+        # block (no Dense between the embedding and the heads) are not supported here rather than guessed
+        if self.input_layers < 1 or self.mid_layers < 1:
+            raise ValueError("NeRFModel needs input_layers >= 1 and mid_layers >= 1")
+        if min(self.hidden_dim, self.color_layer_dim, self.x_freqs, self.d_freqs) < 1:
+            raise ValueError("NeRFModel widths and frequency counts must be positive")
 
     def invalidate_packed(self) -> None:
         """Call after the parameters were modified outside torch (e.g. by lnrf_adam_step)."""
@@ -158,37 +174,69 @@ class NeRFModel(ModelBase):
     def _use_fused(self) -> bool:
         if self.precision not in ("bf16", "fp32"):
             raise ValueError(f"unknown precision {self.precision!r}")
-        return self.precision == "bf16" and self.fused_supported()
+        if self.render_precision not in ("bf16x3", "bf16"):
+            raise ValueError(f"unknown render_precision {self.render_precision!r}")
+        fused = self.precision == "bf16" and self.fused_supported()
+        if self.precision == "bf16" and not fused and not self._warned_dense:
+            self._warned_dense = True
+            warnings.warn("NeRFModel: only the default shape (5, 4, 256, 128, 10, 4) has fused kernels; this shape "
+                          "runs on the generic dense GEMM path (about 10x slower)", RuntimeWarning, stacklevel=3)
+        return fused
 
     # ---- fused bf16 path ----------------------------------------------------------------------
-    def packed_weights(self, flat: torch.Tensor) -> torch.Tensor:
-        """bf16 MFMA-fragment copy of the parameters; rebuilt when the flat buffer changes."""
-        key = (flat.data_ptr(), flat._version, flat.device, self._pack_generation)
-        if self._pack_cache is not None and self._pack_cache[0] == key:
-            return self._pack_cache[1]
+    def packed_weights(self, flat: torch.Tensor, kind: str = "bf16") -> torch.Tensor:
+        """
+        MFMA-fragment copy of the parameters: kind "bf16" (forward + transposed streams, training) or
+        "split" (bf16 hi/lo pairs, rendering).  A small cache maps (storage address, size, version, generation)
+        to the packed buffer.  Every miss packs into a FRESH buffer — a saved backward context may still hold
+        the previous one (e.g. one model instance serving as coarse and fine) — and every entry keeps a
+        reference to its source tensor, so a freed temporary's address cannot come back as a stale hit.
+        """
+        if self._pack_cache is None:
+            self._pack_cache = OrderedDict()
+        key = (kind, flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
+        hit = self._pack_cache.get(key)
+        if hit is not None:
+            self._pack_cache.move_to_end(key)
+            return hit[1]
         shape = self._shape_struct()
-        nbytes = L.lib().lnrf_nerf_packed_bytes(ctypes.byref(shape))
-        packed = (self._pack_cache[1] if self._pack_cache is not None and self._pack_cache[1].device == flat.device
-                  else torch.empty(nbytes, dtype=torch.uint8, device=flat.device))
-        L.check(L.lib().lnrf_nerf_pack_weights(ctypes.byref(shape), L.ptr(flat), L.ptr(packed, torch.uint8),
+        lib = L.lib()
+        if kind == "split":
+            nbytes = lib.lnrf_nerf_packed_split_bytes(ctypes.byref(shape))
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+            L.check(lib.lnrf_nerf_pack_weights_split(ctypes.byref(shape), L.ptr(flat), L.ptr(packed, torch.uint8),
+                                                     L.stream()), "nerf_pack_weights_split")
+        else:
+            nbytes = lib.lnrf_nerf_packed_bytes(ctypes.byref(shape))
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+            L.check(lib.lnrf_nerf_pack_weights(ctypes.byref(shape), L.ptr(flat), L.ptr(packed, torch.uint8),
                                                L.stream()), "nerf_pack_weights")
-        self._pack_cache = (key, packed)
+        self._pack_cache[key] = (flat, packed)
+        while len(self._pack_cache) > 4:
+            self._pack_cache.popitem(last=False)
         return packed
 
     def _fused_fwd(self, flat, m, save, x=None, d=None, rays=None, ts=None):
         shape = self._shape_struct()
-        packed = self.packed_weights(flat)
         dev = flat.device
         density = torch.empty(m, dtype=F32, device=dev)
         rgb = torch.empty((m, 3), dtype=F32, device=dev)
-        save_buf = None
-        if save:
-            nbytes = L.lib().lnrf_nerf_save_bytes(ctypes.byref(shape), m)
-            save_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if rays is not None:
             rstride, t = rays.shape[1] * 3, ts.shape[1]
         else:
             rstride, t = 6, 0
+        if not save and self.render_precision == "bf16x3":
+            packed3 = self.packed_weights(flat, "split")
+            with _prof.section(f"{self.tag}_fwd_split"):
+                L.check(L.lib().lnrf_nerf_mlp_fwd_split(
+                    ctypes.byref(shape), L.ptr(packed3, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride,
+                    L.ptr(ts), t, m, L.ptr(density), L.ptr(rgb), L.stream()), "nerf_mlp_fwd_split")
+            return density, rgb, None
+        packed = self.packed_weights(flat)
+        save_buf = None
+        if save:
+            nbytes = L.lib().lnrf_nerf_save_bytes(ctypes.byref(shape), m)
+            save_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with _prof.section(f"{self.tag}_fwd"):
             L.check(L.lib().lnrf_nerf_mlp_fwd(
                 ctypes.byref(shape), L.ptr(packed, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride,

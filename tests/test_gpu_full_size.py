@@ -56,17 +56,18 @@ def test_full_size_step_properties_and_subset_parity():
     assert (ts_f[:, 1:] >= ts_f[:, :-1]).all()
     probs = ops.termination_probs(ts_f, t_min, t_max, fine["densities"])
     assert (probs.sum(1) - 1).abs().max().item() < 1e-4
-    # oracle on a random subset of rays: same fine ts, same weights (bf16-operand oracle)
+    # oracle on a random subset of rays: same fine ts, same weights; the renderer runs the split-precision kernel,
+    # so the comparison is with the EXACT float64 oracle at north_star's 1e-3
     sel = torch.randperm(N, generator=gen)[:48]
     cf, ff, bg = [t.cpu().double() for t in loop._slices(loop.flat)]
     rays_s = batch[sel.cuda(), :2].cpu().double()
     bbox = torch.tensor([BMIN, BMAX], dtype=F64)
     tmin_s, tmax_s, mask_s = OR.ray_t_range(bbox, rays_s)
     samples = OR.RaySamples(tmin_s, tmax_s, mask_s, ts_f[sel.cuda()].cpu().double())
-    ref, _ = OR.render_rays(OM.make_nerf_fn(ff, OM.bf16_round), bg, rays_s, samples)
+    ref, _ = OR.render_rays(OM.make_nerf_fn(ff), bg, rays_s, samples)
     err = (fine["outputs"][sel.cuda()].cpu().double() - ref["outputs"]).abs().max().item()
-    print(f"full size: subset max |rgb - oracle| = {err:.2e}")
-    assert err < 4e-3
+    print(f"full size: subset max |rgb - exact oracle| = {err:.2e}")
+    assert err < 1e-3
     # one training step at full size: finite losses, parameters move, loss decreases over a few steps
     step = loop.step_fn(BMIN, BMAX)
     first = step(Key(1), batch)

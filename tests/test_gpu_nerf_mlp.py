@@ -4,6 +4,8 @@ dense path, forward and backward, against the oracle on identical weights and po
 
 Tolerances
   fp32 path  vs float64 oracle: 2e-5 abs on rgb/density (well inside the 1e-3 gate of north_star).
+  bf16x3     (split-precision render kernel, the default for every forward without a backward) vs the float64
+             oracle: 5e-5 abs on rgb, 5e-5 relative on density — the reference's fp32 arithmetic to ~16 bits.
   bf16 path  vs the bf16-operand oracle (same roundings, float64 accumulate): 1e-3 abs on rgb.
   bf16 path  vs the float64 oracle: reported, loosely bounded (bf16 has an 8-bit significand).
   gradients  bf16 path vs float64 autograd: relative L2 error per Dense layer < 3e-2.
@@ -25,10 +27,10 @@ def make_points(m, seed=0):
     return x, d, gen
 
 
-def make_model(precision, seed=1, bias_scale=0.1):
+def make_model(precision, seed=1, bias_scale=0.1, render_precision="bf16x3"):
     from learn_nerf.model import NeRFModel
 
-    model = NeRFModel(precision=precision)
+    model = NeRFModel(precision=precision, render_precision=render_precision)
     params = model.init(dict(params=seed))["params"]
     flat = model.flat(params)
     # Flax initialises biases to zero; perturb them so that bias handling is exercised
@@ -54,9 +56,62 @@ def test_fp32_dense_path_forward(m):
     assert torch.allclose(dens.cpu().double(), rd, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("m", [1, 31, 127, 777, 4096, 10000])
+def test_fused_split_precision_forward(m):
+    """lnrf_nerf_mlp_fwd_split (bf16 hi+lo operands, 3 MFMAs per product) against the exact float64 oracle."""
+    model, params, flat = make_model("bf16")
+    x, d, _ = make_points(m, seed=m)
+    dens, rgb, aux = model.apply(dict(params=params), x.cuda(), d.cuda())
+    rd, rr, _ = OM.nerf_mlp(flat.cpu().double(), x.double(), d.double())
+    assert aux == {} and dens.shape == (m, 1) and rgb.shape == (m, 3)
+    err = (rgb.cpu().double() - rr).abs().max().item()
+    derr = ((dens.cpu().double() - rd).abs() / (1 + rd.abs())).max().item()
+    print(f"m={m}: split-precision rgb max|d| vs fp64 oracle {err:.2e}, density rel {derr:.2e}")
+    assert err < 5e-5 and derr < 5e-5
+
+
+def test_split_precision_rays_mode_and_repack():
+    """rays mode == points mode; the packed split stream follows parameter updates (cache keyed on version)."""
+    from learn_nerf import ops
+
+    model, params, flat = make_model("bf16")
+    gen = torch.Generator().manual_seed(5)
+    n, t = 77, 19
+    o = torch.randn(n, 3, generator=gen)
+    dd = torch.randn(n, 3, generator=gen)
+    dd = dd / dd.norm(dim=-1, keepdim=True)
+    batch = torch.stack([o, dd], 1).float().cuda()
+    ts = (torch.rand(n, t, generator=gen) * 2).float().cuda()
+    d1, c1, _, _ = model.forward_rays(flat, batch, ts, save=False)
+    pts, dirs = ops.ray_points(batch, ts)
+    d2, c2, _, _ = model.forward_points(flat, pts.view(-1, 3), dirs.view(-1, 3), save=False)
+    assert torch.allclose(d1.reshape(-1), d2, atol=1e-6, rtol=1e-6) and torch.allclose(c1.reshape(-1, 3), c2, atol=1e-6)
+    flat.mul_(1.01)  # in-place torch op: bumps the version counter, so the next forward repacks
+    d3, c3, _, _ = model.forward_points(flat, pts.view(-1, 3), dirs.view(-1, 3), save=False)
+    rd, rr, _ = OM.nerf_mlp(flat.cpu().double(), pts.view(-1, 3).cpu().double(), dirs.view(-1, 3).cpu().double())
+    assert (c3.cpu().double() - rr).abs().max().item() < 5e-5
+    assert not torch.equal(c3, c2)
+
+
+def test_apply_with_two_plain_dict_param_sets():
+    """model.apply with plain (non-ParamTree) dicts builds temporary flat buffers; a recycled address must not
+    hit the pack cache (stale weights)."""
+    model, params, flat = make_model("bf16")
+    x, d, _ = make_points(300, seed=9)
+    outs = []
+    for scale in (1.0, 0.5):
+        plain = {k: {kk: (vv * scale).clone() for kk, vv in v.items()} for k, v in params.items()}
+        _, rgb, _ = model.apply(dict(params=plain), x.cuda(), d.cuda())
+        _, rr, _ = OM.nerf_mlp(flat.cpu().double() * scale, x.double(), d.double())
+        assert (rgb.cpu().double() - rr).abs().max().item() < 5e-5
+        outs.append(rgb)
+        del plain
+    assert not torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("m", [1, 31, 777, 4096, 10000])
 def test_fused_bf16_forward(m):
-    model, params, flat = make_model("bf16")
+    model, params, flat = make_model("bf16", render_precision="bf16")  # the arithmetic of the training forward
     x, d, _ = make_points(m, seed=m)
     dens, rgb, _ = model.apply(dict(params=params), x.cuda(), d.cuda())
     f64 = flat.cpu().double()
@@ -81,7 +136,7 @@ def test_fused_bf16_forward(m):
 def test_fused_rays_mode_matches_points_mode():
     from learn_nerf import ops
 
-    model, params, flat = make_model("bf16")
+    model, params, flat = make_model("bf16", render_precision="bf16")
     gen = torch.Generator().manual_seed(5)
     n, t = 100, 17
     o = torch.randn(n, 3, generator=gen)

@@ -49,16 +49,27 @@ def split_flat(loop):
     return c.cpu().double(), f.cpu().double(), bg.cpu().double()
 
 
-@pytest.mark.parametrize("precision,n,tc,tf", [("fp32", 96, 16, 32), ("bf16", 96, 16, 32), ("bf16", 256, 64, 128),
-                                               ("fp32", 64, 16, 0)])
-def test_renderer_matches_oracle(precision, n, tc, tf):
+def _models(mode):
+    """mode: "fp32" exact dense path | "bf16x3" default fused path (split-precision render kernel) |
+    "bf16" fused path rendering with the plain bf16 kernel (the arithmetic of the TRAINING forward)."""
     from learn_nerf.model import NeRFModel
+
+    if mode == "fp32":
+        return NeRFModel(precision="fp32"), NeRFModel(precision="fp32")
+    rp = "bf16x3" if mode == "bf16x3" else "bf16"
+    return NeRFModel(render_precision=rp), NeRFModel(render_precision=rp)
+
+
+@pytest.mark.parametrize("mode,n,tc,tf", [("fp32", 96, 16, 32), ("bf16x3", 96, 16, 32), ("bf16x3", 256, 64, 128),
+                                          ("bf16x3", 64, 16, 0), ("bf16", 96, 16, 32), ("bf16", 256, 64, 128),
+                                          ("fp32", 64, 16, 0)])
+def test_renderer_matches_oracle(mode, n, tc, tf):
     from learn_nerf.render import NeRFRenderer
     from learn_nerf.rng import Key, split
     from learn_nerf.train import TrainLoop
 
-    loop = TrainLoop(NeRFModel(precision=precision), NeRFModel(precision=precision), init_rng=3, lr=1e-3,
-                     coarse_ts=tc, fine_ts=tf)
+    coarse, fine = _models(mode)
+    loop = TrainLoop(coarse, fine, init_rng=3, lr=1e-3, coarse_ts=tc, fine_ts=tf)
     boost_density(loop)
     loop.state.params["background"].copy_(torch.tensor([0.2, -0.4, 0.9]))
     batch = make_batch(n)
@@ -72,7 +83,7 @@ def test_renderer_matches_oracle(precision, n, tc, tf):
     uc = torch.from_numpy(philox.ray_uniforms(ck.seed, 0, 0, n, tc)).double()
     uf = torch.from_numpy(philox.ray_uniforms(fk.seed, 1, 0, n, tf)).double()
     cf, ff, bg = split_flat(loop)
-    rnd = OM.bf16_round if precision == "bf16" else None
+    rnd = OM.bf16_round if mode == "bf16" else None
     ref = OR.render_hierarchy(OM.make_nerf_fn(cf, rnd), OM.make_nerf_fn(ff, rnd), bg, torch.tensor(BMIN, dtype=F64),
                               torch.tensor(BMAX, dtype=F64), batch[:, :2].double(), tc, tf, uc, uf)
     exact = ref if rnd is None else OR.render_hierarchy(
@@ -84,20 +95,48 @@ def test_renderer_matches_oracle(precision, n, tc, tf):
         err_x = (got - exact[lvl]["outputs"]).abs().max().item()
         aerr = (out[lvl]["alphas"].cpu().double() - ref[lvl]["alphas"]).abs().max().item()
         cerr = (out[lvl]["coords"].cpu().double() - ref[lvl]["coords"]).abs().max().item()
-        print(f"{precision} {lvl}: rgb max|d| vs oracle {err:.2e} (vs exact fp64 {err_x:.2e}), alpha {aerr:.2e}, "
+        print(f"{mode} {lvl}: rgb max|d| vs oracle {err:.2e} (vs exact fp64 {err_x:.2e}), alpha {aerr:.2e}, "
               f"coords {cerr:.2e}")
-        # north_star gate: rendered RGB within 1e-3 absolute per channel on identical rays, met by the
-        # exact-fp32 path (observed ~5e-6).  The bf16-MFMA path is gated at 4e-3 against the
-        # bf16-operand oracle (rare bf16 rounding flips of hidden units move the fine samples too) and its
-        # deviation from exact arithmetic is printed above ("bf16 vs the 1e-3 gate").
-        tol = 1e-3 if precision == "fp32" else 4e-3
-        assert err < tol, (lvl, err)
-        assert aerr < tol and cerr < 5e-3
-        if precision == "bf16":
-            assert err_x < 1e-2  # reported deviation of the bf16 path from exact arithmetic
+        # north_star gate: rendered RGB within 1e-3 absolute per channel of the reference's fp32 arithmetic on
+        # identical rays, uniforms and weights.  It holds for the exact-fp32 dense path AND for the fused render
+        # kernel ("bf16x3", what NeRFRenderer / render_nerf.py run): both are compared with the EXACT float64
+        # oracle.  The plain bf16 kernel (training forward; render_precision="bf16") has an 8-bit significand and
+        # is compared with an oracle that rounds the same operands, at 4e-3, its distance to exact printed.
+        if mode == "bf16":
+            assert err < 4e-3 and aerr < 4e-3 and cerr < 5e-3, (lvl, err)
+            assert err_x < 1e-2
+        else:
+            assert err < 1e-3, (lvl, err)
+            assert aerr < 1e-3 and cerr < 1e-3
     assert out["fine"]["rgbs"].shape == (n, tc + tf, 3) and out["fine"]["densities"].shape == (n, tc + tf)
     alpha = ref["fine"]["alphas"]
     assert alpha.max() > 0.5 and alpha.min() < 0.1, "test scene must exercise both opaque and empty rays"
+
+
+def test_one_model_instance_as_coarse_and_fine():
+    """TrainLoop(m, m) — legal with the stateless Flax reference (train.py:47-58): the fine forward must not
+    overwrite the packed weights that the coarse backward context still holds."""
+    from learn_nerf.model import NeRFModel
+    from learn_nerf.train import TrainLoop
+
+    n, tc, tf, lr = 96, 16, 32, 1e-3
+    m = NeRFModel()
+    loop = TrainLoop(m, m, init_rng=21, lr=lr, coarse_ts=tc, fine_ts=tf)
+    boost_density(loop)
+    batch = make_batch(n, seed=8)
+    cf, ff, bg = split_flat(loop)
+    assert not torch.equal(cf, ff)
+    uc, uf = uniforms_for(55, n, tc, tf)
+    log = loop.step_fn(BMIN, BMAX)(55, batch.cuda())
+    _, _, ref_log, grads = OT.nerf_train_step(
+        lambda fl: OM.make_nerf_fn(fl, OM.bf16_round), cf, ff, bg, None, 1, lr, torch.tensor(BMIN, dtype=F64),
+        torch.tensor(BMAX, dtype=F64), batch.double(), tc, tf, uc.double(), uf.double())
+    got = loop.grad.cpu().double()
+    nc = cf.numel()
+    for name, g, r in (("coarse", got[:nc], grads[0].reshape(-1)), ("fine", got[nc:2 * nc], grads[1].reshape(-1))):
+        rel = ((g - r).norm() / r.norm()).item()
+        print(f"shared instance, {name}: grad rel err {rel:.2e}")
+        assert rel < 3e-2, (name, rel)
 
 
 @pytest.mark.parametrize("precision,n,tc,tf", [("fp32", 64, 16, 32), ("bf16", 200, 16, 32), ("bf16", 128, 64, 128)])

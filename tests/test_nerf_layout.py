@@ -61,6 +61,22 @@ def test_stream_sizes_and_consumption_order(H):
     assert bseq == sorted(bseq) and bseq[4] == 16  # Dense_11^T uses 4 fragments of its 16-fragment stage
 
 
+def test_split_precision_stream_order(H):
+    """bf16x3 render stream: [hi, lo] fragment pairs in forward order; the weight ring publishes one 16-fragment
+    stage per barrier, so consumption must be monotone and must enter EVERY stage at its first fragment."""
+    n, used = H.lnrf_host_fwd3_frags(), H.lnrf_host_fwd3_used()
+    assert n == 2384 and n % 16 == 0 and used == 2 * 1186
+    seq = [H.lnrf_host_fwd3_seq(c) for c in range(used)]
+    assert seq == sorted(seq) and len(set(seq)) == used and seq[-1] < n
+    entered = [g // 16 for g in seq if g % 16 == 0]
+    assert entered == list(range(n // 16)), "a stage would be skipped or entered mid-way"
+    # pair c (hi, lo) of layer s sits at fwd3_base(s) + 2 * (index inside the layer), i.e. mirrors fwd_seq
+    for s in range(11):
+        c0 = H.lnrf_host_fwd_layer_info(s, 4)
+        assert H.lnrf_host_fwd3_seq(2 * c0) == H.lnrf_host_fwd3_base(s)
+        assert H.lnrf_host_fwd3_seq(2 * c0 + 1) == H.lnrf_host_fwd3_base(s) + 1
+
+
 def test_every_weight_is_packed_exactly_once(H):
     counts = np.zeros(593_924, np.int32)
     for g in range(1200):
