@@ -4,7 +4,9 @@ bench.py — throughput of the NeRF train step (learn_nerf/train.py:78-112 resta
 on N GPUs of one node.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either the driver's launch (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+  --gpus N ...), or plain `python bench.py --gpus N`, which starts that launcher itself as a child process before
+  anything touches the GPU.  The run fails if the RCCL process group does not have exactly N ranks.
 
 Workload (BASELINE.json configs[1], the metric's own config): vanilla NeRF, 4096 rays per GPU,
 64 coarse + 128 fine samples per ray (192 ray-samples per ray, 256 MLP evaluations per ray),
@@ -13,11 +15,17 @@ targets, Flax-default initial weights.  One step = forward + backward + [RCCL al
 Rays shard data-parallel: every rank draws its own 4096 rays (weak scaling), gradients are
 all-reduced (sum) over RCCL and averaged inside the fused Adam kernel.
 
-Rank 0 prints ONE JSON line (see the task contract) with two extra objects:
-  roofline     — the dominant kernel family, algorithmic FLOPs / measured HIP-event time vs the
-                 dense bf16 MFMA peak of MI355X (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md)
+Rank 0 prints ONE JSON line (see the task contract) with these extra objects:
+  roofline     — SURVEY.md 8(d): configs[1] is MFMA-bound, so the dominant kernel family's algorithmic FLOP per
+                 launch / its mean HIP-event time in the timed region vs the dense bf16 MFMA peak of MI355X
+                 (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from the
+                 rocprofv3 PMC summary named in `traffic_source` (a separate profiling run, not this one)
+  roofline_hbm — the same kernel against the HBM roof (its design bytes per launch / time / 8 TB/s)
   cpu_baseline — the oracle's torch-CPU fp32 restatement of the same step on a bounded sample
                  (rank 0, N = 1 only); a reported baseline, not the optimisation target.
+  other_workloads (N = 1) — short legs of BASELINE configs[2] (instant_ngp, HBM roofline) and configs[3] (ref_nerf)
+  inference_mlp / inference_mlp_split — the render-path forward: plain bf16 and the split-precision kernel that
+                 NeRFRenderer runs (rendered RGB within 1e-3 of fp32)
 """
 import argparse
 import json
@@ -87,11 +95,106 @@ def cpu_baseline(n_rays=1024, steps=4):
                        f"step (oracle/), mean of {steps} steps after 1 warm-up, {sec:.2f} s/step")
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a
+    CHILD process (nothing in this process has touched the GPU yet) and pass its exit code on."""
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def build_loop(workload, precision, table_log2, device):
+    from learn_nerf.model import NeRFModel
+    from learn_nerf.train import TrainLoop
+
+    if workload == "ngp":
+        from learn_nerf.instant_ngp import InstantNGPModel
+
+        def ngp(levels):  # scripts/train_nerf.py:150-161 with the table size of BASELINE configs[2]
+            return InstantNGPModel(table_sizes=[2 ** table_log2] * levels,
+                                   grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], bbox_min=BBOX_MIN,
+                                   bbox_max=BBOX_MAX, precision=precision)
+
+        return TrainLoop(ngp(6), ngp(16), init_rng=0, lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, adam_eps=1e-15,
+                         adam_b1=0.9, adam_b2=0.99, device=device)
+    if workload == "refnerf":
+        from learn_nerf.ref_nerf import RefNERFModel
+
+        return TrainLoop(RefNERFModel(sh_degree=4, precision=precision),
+                         RefNERFModel(sh_degree=4, precision=precision), init_rng=0, lr=1e-4, coarse_ts=COARSE,
+                         fine_ts=FINE, device=device)
+    return TrainLoop(NeRFModel(precision=precision), NeRFModel(precision=precision), init_rng=0,
+                     lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, device=device)
+
+
+def ngp_roofline(fams, m_c, m_f):
+    """gather/scatter roofline: L * 8 corners * F * 4 B per evaluation; the scatter-add counts 2x"""
+    for name, v in fams.items():
+        lv = 6 if name.startswith("coarse") else 16
+        m = m_c if name.startswith("coarse") else m_f
+        if name.endswith("hashgrid_fwd"):
+            v["GBps"] = round(m * lv * 8 * 2 * 4 / (v["ms"] * 1e-3) / 1e9, 1)
+        elif name.endswith("hashgrid_bwd"):
+            v["GBps"] = round(2 * m * lv * 8 * 2 * 4 / (v["ms"] * 1e-3) / 1e9, 1)
+    hg = {k: v for k, v in fams.items() if "GBps" in v}
+    if not hg:
+        return None
+    dom = max(hg, key=lambda k: hg[k]["ms"])
+    return dict(bound="hbm", kernel=dom, achieved=hg[dom]["GBps"], peak=8000.0, unit="GB/s",
+                frac=round(hg[dom]["GBps"] / 8000.0, 4), traffic=None)
+
+
+def short_leg(workload, n, device, table_log2, steps=10, warmup=3):
+    """A few steps of another BASELINE config on this GPU (N = 1 only), so that the driver's record covers it."""
+    from learn_nerf import _prof
+    from learn_nerf.rng import Key
+
+    loop = build_loop(workload, "bf16", table_log2, device)
+    step = loop.step_fn(BBOX_MIN, BBOX_MAX)
+    batch = synthetic_batch(n, 1000, device)
+    for i in range(warmup):
+        step(Key(i), batch)
+    torch.cuda.synchronize()
+    _prof.enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(Key(warmup + i), batch)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    prof = _prof.summary()
+    _prof.enable(False)
+    fams = {k: dict(ms=round(v[1], 4), calls_per_step=v[0] / steps) for k, v in prof.items()}
+    out = dict(ms_per_step=round(ms, 3), value=round(n * (COARSE + FINE) / (ms * 1e-3), 1), unit="ray-samples/s",
+               steps=steps, warmup=warmup)
+    if workload == "ngp":
+        # whole step against the HBM roof: 663,552 algorithmic bytes per ray (SURVEY 8d)
+        out["step_hbm"] = dict(achieved=round(n * 663_552 / (ms * 1e-3) / 1e9, 1), peak=8000.0, unit="GB/s",
+                               frac=round(n * 663_552 / (ms * 1e-3) / 8e12, 4))
+        out["roofline"] = ngp_roofline(fams, n * COARSE, n * (COARSE + FINE))
+        out["config"] = f"instant_ngp hash-grid L=6/16, T=2^{table_log2} (BASELINE configs[2])"
+    else:
+        out["roofline"] = None  # generic GEMM chain, no fused kernel yet: no roofline model (DESIGN.md)
+        out["config"] = "ref_nerf.py RefNERFModel sh_degree 4 incl. normal losses (BASELINE configs[3])"
+    out["kernels"] = fams
+    del loop, step
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="nerf", choices=["nerf", "ngp", "refnerf"],
@@ -100,7 +203,12 @@ def main():
     ap.add_argument("--table_log2", type=int, default=19, help="ngp: log2 of the hash table size (configs[2]: 19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short ngp / refnerf legs")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # before any GPU call in this process
 
     # Libraries (e.g. RCCL's start-up banner) write to the C-level stdout; keep stdout clean for the one
     # JSON line by pointing fd 1 at stderr until the result is printed.
@@ -121,33 +229,17 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} ranks")
+    if dist is not None and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: the RCCL process group has {dist.get_world_size()} ranks, expected {args.gpus}")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible")
 
     from learn_nerf import _prof
-    from learn_nerf.model import NeRFModel
-    from learn_nerf.train import TrainLoop
 
     n = args.rays
-    if args.workload == "ngp":
-        from learn_nerf.instant_ngp import InstantNGPModel
-
-        def ngp(levels):  # scripts/train_nerf.py:150-161 with the table size of BASELINE configs[2]
-            return InstantNGPModel(table_sizes=[2 ** args.table_log2] * levels,
-                                   grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], bbox_min=BBOX_MIN,
-                                   bbox_max=BBOX_MAX, precision=args.precision)
-
-        loop = TrainLoop(ngp(6), ngp(16), init_rng=0, lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, adam_eps=1e-15,
-                         adam_b1=0.9, adam_b2=0.99, device=device)
-    elif args.workload == "refnerf":
-        from learn_nerf.ref_nerf import RefNERFModel
-
-        loop = TrainLoop(RefNERFModel(sh_degree=4, precision=args.precision),
-                         RefNERFModel(sh_degree=4, precision=args.precision), init_rng=0, lr=1e-4, coarse_ts=COARSE,
-                         fine_ts=FINE, device=device)
-    else:
-        loop = TrainLoop(NeRFModel(precision=args.precision), NeRFModel(precision=args.precision), init_rng=0,
-                         lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, device=device)
+    loop = build_loop(args.workload, args.precision, args.table_log2, device)
     if world > 1:  # same initial parameters everywhere (init is seeded, broadcast for safety)
         dist.broadcast(loop.flat, src=0)
     step = loop.step_fn(BBOX_MIN, BBOX_MAX)
@@ -160,6 +252,23 @@ def main():
 
     from learn_nerf.rng import Key
 
+    comm_abi_check = None
+    if world > 1:
+        # exercise the C-ABI RCCL entries (lnrf_comm_*) across the real ranks, outside the timed region: the same
+        # vector reduced through them and through torch.distributed must agree
+        try:
+            from learn_nerf import parallel as _par
+
+            comm = _par.AbiComm.from_process_group()
+            probe = torch.arange(4096, dtype=torch.float32, device=device) * (rank + 1)
+            ref = probe.clone()
+            comm.all_reduce_sum_(probe)
+            dist.all_reduce(ref)
+            torch.cuda.synchronize()
+            comm_abi_check = "ok" if torch.equal(probe, ref) else "MISMATCH vs torch.distributed"
+            comm.destroy()
+        except Exception as exc:
+            comm_abi_check = f"{type(exc).__name__}: {exc}"
     for i in range(args.warmup):
         step(Key(i, ray_offset=rank * n), batch)
     barrier()
@@ -196,24 +305,12 @@ def main():
                 flops = None
             fams[name] = dict(ms=round(ms, 4), calls_per_step=cnt / args.steps,
                               tflops=None if flops is None else round(flops / (ms * 1e-3) / 1e12, 1))
-        roofline = None
+        roofline, roofline_hbm = None, None
         timed = {k: v for k, v in fams.items() if v["tflops"] is not None}
         if args.workload == "ngp":
-            # gather/scatter roofline: L*8 corners*F*4 B per evaluation; scatter-add counted as 2x
-            for name, v in fams.items():
-                lv = 6 if name.startswith("coarse") else 16
-                m = m_c if name.startswith("coarse") else m_f
-                if name.endswith("hashgrid_fwd"):
-                    v["GBps"] = round(m * lv * 8 * 2 * 4 / (v["ms"] * 1e-3) / 1e9, 1)
-                elif name.endswith("hashgrid_bwd"):
-                    v["GBps"] = round(2 * m * lv * 8 * 2 * 4 / (v["ms"] * 1e-3) / 1e9, 1)
-            hg = {k: v for k, v in fams.items() if "GBps" in v}
-            if hg:
-                dom = max(hg, key=lambda k: hg[k]["ms"])
-                roofline = dict(bound="hbm", kernel=dom, achieved=hg[dom]["GBps"], peak=8000.0, unit="GB/s",
-                                frac=round(hg[dom]["GBps"] / 8000.0, 4), traffic=None)
+            roofline = ngp_roofline(fams, m_c, m_f)
         elif timed:
-            # Algorithmic HBM bytes per 32-evaluation tile of each kernel family:
+            # Design HBM bytes per 32-evaluation tile of each kernel family:
             # forward writes the 167 KiB save block, the backward chain reads 9 KiB of masks and writes
             # 156 KiB of dy, the weight-gradient kernel reads X and dy fragments (344 KiB).
             tile_bytes = {"_fwd": 167 * 1024, "_bwd_chain": (156 + 9) * 1024, "_bwd_weights": 344 * 1024}
@@ -223,19 +320,26 @@ def main():
                     if name.endswith(suffix):
                         v["GBps"] = round((m / 32) * b / (v["ms"] * 1e-3) / 1e9, 1)
             dom = max(timed, key=lambda k: timed[k]["ms"])
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-            if os.path.exists(pmc) and n == RAYS_PER_GPU:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-            if dom.endswith("_bwd_weights"):
-                # the dominant kernel streams its operands once from HBM (128 FLOP/B on bf16 dumps): HBM roofline
-                roofline = dict(bound="hbm", kernel=dom, achieved=timed[dom]["GBps"], peak=8000.0, unit="GB/s",
-                                frac=round(timed[dom]["GBps"] / 8000.0, 4), traffic=traffic,
-                                mfma_tflops=timed[dom]["tflops"])
-            else:
-                achieved = timed[dom]["tflops"]
-                roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_FLOPS / 1e12,
-                                unit="TFLOP/s", frac=round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), traffic=traffic)
+            traffic, traffic_source = None, None
+            for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+                pmc = os.path.join(ROOT, "profiles", cand)
+                if os.path.exists(pmc) and n == RAYS_PER_GPU:
+                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_source = (f"profiles/{cand}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                          "earlier run of this command (gfx950 FETCH x2 correction), NOT measured in "
+                                          "this run")
+                        break
+            # configs[1] is MFMA-bound -> algorithmic FLOP of the dominant kernel / its time / bf16 peak
+            achieved = timed[dom]["tflops"]
+            roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=PEAK_BF16_FLOPS / 1e12,
+                            unit="TFLOP/s", frac=round(achieved / (PEAK_BF16_FLOPS / 1e12), 4), traffic=traffic,
+                            traffic_source=traffic_source, ms_per_launch=timed[dom]["ms"])
+            if "GBps" in timed[dom]:
+                roofline_hbm = dict(bound="hbm", kernel=dom, achieved=timed[dom]["GBps"], peak=8000.0, unit="GB/s",
+                                    frac=round(timed[dom]["GBps"] / 8000.0, 4),
+                                    note="design bytes per launch (DESIGN.md section 4) / time: the dump traffic "
+                                         "this kernel streams, not an algorithmic minimum")
         step_tflops = (value / world) * FLOP_TRAIN_PER_RAY_SAMPLE / 1e12
         out = dict(
             metric="ray-samples/s (NeRF train step: fwd + bwd + Adam, 4096 rays x 192 samples per GPU)",
@@ -252,32 +356,50 @@ def main():
                         parallelism=f"dp{world}", precision=args.precision + " MFMA, fp32 accumulate/master weights"
                         if args.precision == "bf16" else "fp32 (f32 MFMA)"),
             roofline=roofline,
+            roofline_hbm=roofline_hbm,
             step_mfma=dict(achieved=round(step_tflops, 1), peak=PEAK_BF16_FLOPS / 1e12, unit="TFLOP/s",
                            frac=round(step_tflops / (PEAK_BF16_FLOPS / 1e12), 4),
                            note="whole step per GPU: ray-samples/s x 4,641,792 algorithmic FLOP (SURVEY 8d)"),
+            comm_abi_check=comm_abi_check,
             kernels=fams,
             losses={k: round(float(v), 5) for k, v in log.items()},
         )
         if args.workload != "nerf":
             del out["step_mfma"]  # the FLOP model is the vanilla NeRFModel's; the hash-grid step is gather/scatter bound
         if args.workload == "nerf" and args.precision == "bf16":
-            # the same fused MLP kernel without the activation dumps (what render_nerf.py runs): compute-bound
+            # the render path: the fused forward without activation dumps, plain bf16 and split precision
             from learn_nerf import ops as _ops
 
             _, _, _, ts_c = _ops.ray_aabb_stratified(batch, BBOX_MIN, BBOX_MAX, COARSE + FINE, seed=1)
             c_flat = loop._slices(loop.flat)[1]
-            for _ in range(3):
-                loop.fine.forward_rays(c_flat, batch, ts_c, save=False)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                loop.fine.forward_rays(c_flat, batch, ts_c, save=False)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
-            tf = m_f * FLOP_FWD_PER_EVAL / (ms * 1e-3) / 1e12
-            out["inference_mlp"] = dict(ms=round(ms, 4), tflops=round(tf, 1), frac_of_mfma_peak=round(tf / 2500.0, 4),
-                                        note="fine-pass NeRFModel forward, no activation save (render path)")
+            for key, rp, note in (("inference_mlp", "bf16", "fine-pass NeRFModel forward, no activation save, plain "
+                                   "bf16 operands (render_precision='bf16')"),
+                                  ("inference_mlp_split", "bf16x3", "the kernel NeRFRenderer / render_nerf.py run: bf16 "
+                                   "hi+lo operands, 3 MFMAs per product (rendered RGB within 1e-3 of fp32); tflops = "
+                                   "algorithmic fp32-equivalent FLOP, MFMA work is 3x that")):
+                loop.fine.render_precision = rp
+                for _ in range(3):
+                    loop.fine.forward_rays(c_flat, batch, ts_c, save=False)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    loop.fine.forward_rays(c_flat, batch, ts_c, save=False)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                tf = m_f * FLOP_FWD_PER_EVAL / (ms * 1e-3) / 1e12
+                out[key] = dict(ms=round(ms, 4), tflops=round(tf, 1), frac_of_mfma_peak=round(tf / 2500.0, 4), note=note)
+            loop.fine.render_precision = "bf16x3"
+        if world == 1 and args.workload == "nerf" and not args.no_other_workloads:
+            del step
+            loop = None
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {}
+            for wl in ("ngp", "refnerf"):
+                try:
+                    out["other_workloads"][wl] = short_leg(wl, n, device, args.table_log2)
+                except Exception as exc:  # a broken secondary leg must not hide the headline measurement
+                    out["other_workloads"][wl] = dict(error=f"{type(exc).__name__}: {exc}")
         if world == 1 and not args.no_cpu_baseline and args.workload == "nerf":
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

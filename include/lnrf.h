@@ -68,6 +68,13 @@ int lnrf_camera_rays(const float* origin, const float* x_axis, const float* y_ax
                      float x_fov, float y_fov, int32_t width, int32_t height, float* rays,
                      lnrf_stream_t stream);
 
+/* The shuffled batch iterator's row movement (ShuffledDataset.iterate_batches, dataset.py:222-240: the reference
+ * permutes a shard and concatenates it to the pending rows on the host for every batch): with the shards resident in
+ * HBM, out[i, :] = src[idx[i], :] for i < n, rows of row_floats fp32 (9 = origin, direction, colour).  idx: int32
+ * row numbers in [0, n_src); a row number outside that range writes zeros (never reads out of bounds). */
+int lnrf_gather_rows(const float* src, int64_t n_src, int32_t row_floats, const int32_t* idx, int64_t n,
+                     float* out, lnrf_stream_t stream);
+
 /* RaySamples.stratified_sampling (render.py:121-143) from given t_min/t_max. */
 int lnrf_stratified(const float* t_min, const float* t_max, int64_t n_rays, int32_t count,
                     const float* u, uint64_t seed, uint32_t stream_id, int64_t ray_offset,
@@ -329,6 +336,24 @@ int lnrf_nerf_mlp_bwd_chain(const lnrf_nerf_shape* shape, const void* packed, co
 /* Part 2: grads += X_l^T dy_l for every Dense kernel and sum_m dy_l for every bias. */
 int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
                               int64_t m, float* grads, lnrf_stream_t stream);
+
+/* ------------------------------------------------------- data-parallel exchange ---- */
+
+/* One process per GPU; rays shard across ranks and the ONLY exchange of a training step is one all-reduce (sum) of
+ * the flat fp32 gradient over RCCL/xGMI, between the backward pass and Adam — the data-parallel form of
+ * TrainLoop.step_fn (train.py:85-106; the reference itself is single-device).  The mean over ranks is
+ * lnrf_adam_step's grad_scale = 1/world.  The communicator is an opaque handle (the only persistent object the
+ * library creates).  Bootstrap: rank 0 calls lnrf_comm_get_unique_id and hands the LNRF_COMM_UNIQUE_ID_BYTES bytes to
+ * the other ranks by any channel (file, TCP store); then EVERY rank calls lnrf_comm_init (collective; binds to the
+ * calling thread's current HIP device).  Errors of RCCL are returned as positive ncclResult_t values. */
+#define LNRF_COMM_UNIQUE_ID_BYTES 128
+typedef struct lnrf_comm* lnrf_comm_t;
+int lnrf_comm_get_unique_id(void* unique_id /* (host) LNRF_COMM_UNIQUE_ID_BYTES bytes out */);
+int lnrf_comm_init(const void* unique_id /* (host) */, int32_t rank, int32_t world, lnrf_comm_t* comm_out);
+/* in-place sum over all ranks of buf[n] (device), enqueued on `stream` */
+int lnrf_comm_allreduce(lnrf_comm_t comm, float* buf, int64_t n, lnrf_stream_t stream);
+int lnrf_comm_info(lnrf_comm_t comm, int32_t* rank, int32_t* world);
+int lnrf_comm_destroy(lnrf_comm_t comm);
 
 /* ------------------------------------------------------------- optimiser ---- */
 

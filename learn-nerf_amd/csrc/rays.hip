@@ -478,6 +478,20 @@ __global__ void camera_rays_kernel(Camera cam, int width, int height, float* __r
   }
 }
 
+// out[i, :] = src[idx[i], :]: one thread per output float, so the stores are fully coalesced and the 36-byte source
+// rows are read by 9 neighbouring lanes
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t n_src, int row_floats,
+                                   const int32_t* __restrict__ idx, int64_t n, float* __restrict__ out) {
+  const int64_t total = n * row_floats;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / row_floats;
+    const int f = (int)(e - i * row_floats);
+    const int64_t r = idx[i];
+    out[e] = (r >= 0 && r < n_src) ? src[r * row_floats + f] : 0.0f;
+  }
+}
+
 }  // namespace lnrf
 
 using namespace lnrf;
@@ -630,6 +644,17 @@ extern "C" int lnrf_bin_edges(const float* ts, const float* t_min, const float* 
   if (n_rays == 0 || t == 0) return LNRF_OK;
   hipLaunchKernelGGL(bin_edges_kernel, dim3(grid_for(n_rays * t, 256)), dim3(256), 0, as_stream(stream), ts,
                      t_min, t_max, n_rays, t, starts, ends);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_gather_rows(const float* src, int64_t n_src, int32_t row_floats, const int32_t* idx, int64_t n,
+                                float* out, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(n >= 0 && n_src >= 0 && row_floats >= 1, "bad sizes");
+  if (n == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(src && idx && out, "null pointer");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * row_floats, 256)), dim3(256), 0, as_stream(stream), src,
+                     n_src, (int)row_floats, idx, n, out);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }

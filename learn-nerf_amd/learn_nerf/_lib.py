@@ -43,6 +43,7 @@ PROTOTYPES = {
     "lnrf_ray_aabb_stratified": (c_int32, [_P, c_int64, c_int64, _F3, _F3, c_float, c_float, c_int32, _P,
                                            c_uint64, c_uint32, c_int64, _P, _P, _P, _P, _P]),
     "lnrf_camera_rays": (c_int32, [_F3, _F3, _F3, _F3, c_float, c_float, c_int32, c_int32, _P, _P]),
+    "lnrf_gather_rows": (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "lnrf_stratified": (c_int32, [_P, _P, c_int64, c_int32, _P, c_uint64, c_uint32, c_int64, _P, _P]),
     "lnrf_ray_points": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P]),
     "lnrf_fine_sample": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_int32, _P,
@@ -100,6 +101,11 @@ PROTOTYPES = {
                                        c_int32, c_int32, _P]),
     "lnrf_set_dense_precision": (c_int32, [c_int32]),
     "lnrf_get_dense_precision": (c_int32, []),
+    "lnrf_comm_get_unique_id": (c_int32, [_P]),
+    "lnrf_comm_init": (c_int32, [_P, c_int32, c_int32, POINTER(c_void_p)]),
+    "lnrf_comm_allreduce": (c_int32, [_P, _P, c_int64, _P]),
+    "lnrf_comm_info": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32)]),
+    "lnrf_comm_destroy": (c_int32, [_P]),
     "lnrf_adam_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
                                  c_float, _P]),
     "lnrf_sq_norm": (c_int32, [_P, c_int64, _P, _P]),

@@ -55,6 +55,15 @@ def camera_rays(origin, x_axis, y_axis, z_axis, x_fov: float, y_fov: float, widt
     return rays
 
 
+def gather_rows_into(src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[i, :] = src[idx[i], :] for fp32 row matrices on the GPU (the shuffled batch iterator, dataset.py:222-229)."""
+    if src.dim() != 2 or out.dim() != 2 or src.shape[1] != out.shape[1] or idx.shape[0] != out.shape[0]:
+        raise ValueError("gather_rows_into: shape mismatch")
+    L.check(L.lib().lnrf_gather_rows(L.ptr(src), src.shape[0], src.shape[1], L.ptr(idx, torch.int32), idx.shape[0],
+                                     L.ptr(out), L.stream()), "gather_rows")
+    return out
+
+
 def stratified(t_min, t_max, count: int, u=None, seed: int = 0, stream_id: int = 0, ray_offset: int = 0):
     n = t_min.shape[0]
     ts = torch.empty((n, count), dtype=F32, device=_dev(t_min))

@@ -5,7 +5,9 @@ batch [N,3,3] is split into contiguous shards and the only exchange per step is 
 of the flat fp32 gradient buffer over RCCL (backend "nccl" on ROCm) — or gloo on CPU in the tests.
 The mean over ranks is folded into the fused Adam kernel (grad_scale = 1/world).
 """
+import ctypes
 import os
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -63,6 +65,96 @@ def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     if d is not None and d.get_world_size() > 1:
         d.all_reduce(flat)
     return flat
+
+
+class AbiComm:
+    """
+    RCCL communicator behind the C ABI (include/lnrf.h: lnrf_comm_get_unique_id / init / allreduce / destroy) —
+    the exchange step as a non-torch caller of liblnrf.so would run it.  Bootstrap = hand rank 0's 128-byte unique
+    id to every rank: from_process_group() uses an existing torch.distributed group for that, from_file() a shared
+    path (no torch.distributed at all).  The torch.distributed all-reduce (also RCCL) stays the default backend of
+    reduce_gradient_; use_abi_comm(comm) switches the gradient exchange to this handle.
+    """
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        from . import _lib as L
+
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be LNRF_COMM_UNIQUE_ID_BYTES = 128 bytes")
+        self._L = L
+        handle = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        L.check(L.lib().lnrf_comm_init(buf, rank, world, ctypes.byref(handle)), "comm_init")
+        self._handle = handle
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        from . import _lib as L
+
+        buf = ctypes.create_string_buffer(128)
+        L.check(L.lib().lnrf_comm_get_unique_id(buf), "comm_get_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls) -> "AbiComm":
+        d = dist_module()
+        if d is None:
+            return cls(cls.new_unique_id(), 0, 1)
+        box = [cls.new_unique_id() if d.get_rank() == 0 else None]
+        d.broadcast_object_list(box, src=0)
+        return cls(box[0], d.get_rank(), d.get_world_size())
+
+    @classmethod
+    def from_file(cls, path: str, rank: int, world: int, timeout_s: float = 120.0) -> "AbiComm":
+        if rank == 0:
+            with open(path + ".tmp", "wb") as fh:
+                fh.write(cls.new_unique_id())
+            os.replace(path + ".tmp", path)
+        deadline = time.time() + timeout_s
+        while not os.path.exists(path):
+            if time.time() > deadline:
+                raise TimeoutError(f"rank 0 never wrote the RCCL unique id to {path}")
+            time.sleep(0.05)
+        with open(path, "rb") as fh:
+            return cls(fh.read(), rank, world)
+
+    def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        L = self._L
+        L.check(L.lib().lnrf_comm_allreduce(self._handle, L.ptr(flat), flat.numel(), L.stream()), "comm_allreduce")
+        return flat
+
+    def destroy(self) -> None:
+        if self._handle is not None:
+            self._L.check(self._L.lib().lnrf_comm_destroy(self._handle), "comm_destroy")
+            self._handle = None
+
+
+_abi_comm: Optional[AbiComm] = None
+
+
+def use_abi_comm(comm: Optional[AbiComm]) -> None:
+    """Route reduce_gradient_ through a C-ABI communicator (None: back to torch.distributed)."""
+    global _abi_comm
+    _abi_comm = comm
+
+
+def reduce_gradient_(flat: torch.Tensor) -> float:
+    """
+    The ONE exchange of a data-parallel step: in-place all-reduce (sum) of the flat gradient — over the C-ABI
+    RCCL communicator when use_abi_comm() installed one, else over the default torch.distributed process group
+    (RCCL on GPUs, gloo on CPU tensors), issued whenever a group exists, also with a single rank, so the collective
+    path is exercised by every torchrun launch.  Returns the factor 1/world that the caller folds into Adam
+    (grad_scale) and into the logged grad_norm.
+    """
+    if _abi_comm is not None:
+        _abi_comm.all_reduce_sum_(flat)
+        return 1.0 / _abi_comm.world
+    d = dist_module()
+    if d is None:
+        return 1.0
+    d.all_reduce(flat)
+    return 1.0 / d.get_world_size()
 
 
 def grad_scale() -> float:

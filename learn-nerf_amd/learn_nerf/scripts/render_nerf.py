@@ -5,7 +5,6 @@ Rendering CLI with the command line of the reference's scripts/render_nerf.py: f
 `argparser()` and `RenderSession` keep their names because the reference's pan / spin scripts build on them.
 """
 import argparse
-import pickle
 import random
 
 import numpy as np
@@ -15,7 +14,7 @@ from learn_nerf.dataset import CameraView, ModelMetadata
 from learn_nerf.render import NeRFRenderer
 from learn_nerf.rng import Key
 from learn_nerf.scripts.train_nerf import add_model_args, create_model
-from learn_nerf.train import _tree_from_host
+from learn_nerf.train import load_params
 
 RENDER_FLAGS = (
     ("--seed", int, None, None),
@@ -37,14 +36,6 @@ def argparser() -> argparse.ArgumentParser:
     return parser
 
 
-def _load_params(path: str, coarse, fine, device):
-    with open(path, "rb") as handle:
-        blob = pickle.load(handle)  # written by TrainLoop.save: NumPy leaves under the reference's tree names
-    return dict(coarse=coarse.tree(_tree_from_host(blob["coarse"], coarse).to(device)),
-                fine=fine.tree(_tree_from_host(blob["fine"], fine).to(device)),
-                background=torch.as_tensor(blob["background"], dtype=torch.float32).to(device))
-
-
 class RenderSession:
     """Loads a checkpoint once, renders any number of camera views, then writes them into one PNG."""
 
@@ -54,7 +45,7 @@ class RenderSession:
         print("loading model...")
         self.device = torch.device("cuda", torch.cuda.current_device())
         coarse, fine, _ = create_model(args, self.metadata)
-        params = _load_params(args.model_path, coarse, fine, self.device)
+        params = load_params(args.model_path, coarse, fine, self.device)
         self.renderer = NeRFRenderer(coarse=coarse, fine=fine, coarse_params=params["coarse"],
                                      fine_params=params["fine"], background=params["background"],
                                      bbox_min=self.metadata.bbox_min, bbox_max=self.metadata.bbox_max,
@@ -68,7 +59,7 @@ class RenderSession:
 
     def render_view(self, view: CameraView):
         width, height, step = self.args.width, self.args.height, self.args.batch_size
-        rays = view.bare_rays(width, height).to(self.device)
+        rays = view.bare_rays(width, height, device=self.device)  # lnrf_camera_rays: generated on the GPU
         pieces = []
         for start in range(0, rays.shape[0], step):
             self.key, slice_key = self.key.split(2)

@@ -55,7 +55,7 @@ class DatasetRenderSession(RenderSession):
         return self.renderer.render_rays(key, rays)["fine"]
 
     def render_view_with_depth(self, view: CameraView, size: int, max_depth: float):
-        rays = view.bare_rays(size, size).to(self.device)
+        rays = view.bare_rays(size, size, device=self.device)  # lnrf_camera_rays: generated on the GPU
         colors, depths = [], []
         for start in range(0, rays.shape[0], self.args.batch_size):
             self.key, slice_key = self.key.split(2)

@@ -1,7 +1,7 @@
 """
 Training CLI with the command line of the reference's scripts/train_nerf.py (same flag names, defaults,
 positional `data_dir`, `step {i}: k=v ...` log lines, resume-if-checkpoint-exists, periodic save), driving
-the HIP train step.  Extra, additive flags: --precision, --max_steps.  Under torchrun every global batch is
+the HIP train step.  Extra, additive flags: --precision, --max_steps, --table_log2.  Under torchrun every global batch is
 sharded over the ranks and gradients are all-reduced over RCCL.
 """
 import argparse
@@ -41,12 +41,15 @@ def add_model_args(parser: argparse.ArgumentParser):
         parser.add_argument(switch, action="store_true")
     parser.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                         help="(additive) NeRFModel arithmetic: fused bf16 MFMA kernels or exact fp32")
+    parser.add_argument("--table_log2", type=int, default=18,
+                        help="(additive) --instant_ngp: log2 of the hash-table size per level; the reference "
+                             "hard-codes 2**18 (scripts/train_nerf.py:150-161), BASELINE configs[2] uses 19")
 
 
 def create_model(args: argparse.Namespace, metadata: ModelMetadata) -> Tuple[ModelBase, ModelBase, Dict[str, Any]]:
     """
     (coarse, fine, extra TrainLoop kwargs) with the hyper-parameters hard-coded by the reference
-    (scripts/train_nerf.py:141-170): hash grids of 6 / 16 levels, 2^18 entries, grid 2^(4 + i//2),
+    (scripts/train_nerf.py:141-170): hash grids of 6 / 16 levels, 2^18 entries (--table_log2), grid 2^(4 + i//2),
     Adam(0.9, 0.99, eps 1e-15) for --instant_ngp; sh_degree 4 for --ref_nerf.
     """
     use_ref = bool(getattr(args, "ref_nerf", False))
@@ -56,7 +59,8 @@ def create_model(args: argparse.Namespace, metadata: ModelMetadata) -> Tuple[Mod
 
         factory = partial(InstantNGPRefNERFModel, sh_degree=4) if use_ref else InstantNGPModel
         box = dict(bbox_min=tuple(metadata.bbox_min), bbox_max=tuple(metadata.bbox_max), precision=precision)
-        pair = [factory(table_sizes=[2 ** 18] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], **box)
+        table = 2 ** int(getattr(args, "table_log2", 18))
+        pair = [factory(table_sizes=[table] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)], **box)
                 for levels in (6, 16)]
         return pair[0], pair[1], dict(adam_eps=1e-15, adam_b1=0.9, adam_b2=0.99)
     if use_ref:
@@ -121,8 +125,10 @@ def main():
     test_batches = None
     if test_data is not None:
         test_batches = test_data.iterate_batches(os.path.join(args.test_data_dir, "shuffled"), test_data_key.seed,
-                                                 test_bs)
-    batches = data.iterate_batches(os.path.join(args.data_dir, "shuffled"), data_key.seed, args.batch_size)
+                                                 test_bs, device=loop.device)
+    # shards are uploaded once and every batch is gathered on the GPU (dataset.ShuffledDataset._iterate_on_device)
+    batches = data.iterate_batches(os.path.join(args.data_dir, "shuffled"), data_key.seed, args.batch_size,
+                                   device=loop.device)
     for i, batch in enumerate(batches):
         step_key, test_key, key = key.split(3)
         report = {}

@@ -11,10 +11,10 @@ Parameters {coarse, fine, background} are views of ONE flat fp32 buffer; so are 
 and the Adam moments.
 """
 import os
-import pickle
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _prof
@@ -114,32 +114,37 @@ class TrainLoop:
         Save the model parameters to a file (atomic rename like train.py:62-69).  Besides the reference's
         params tree {"coarse", "fine", "background"} the file also keeps the Adam moments and step count
         (the reference drops them, so every resume restarts Adam's bias correction).
+        The container is a NumPy .npz archive (arrays only, read back with allow_pickle=False) whatever the
+        file is called — the reference pickles a jax pytree, which needs JAX to read and executes code on load.
+        Keys: "format", "background", "opt/step", "opt/m", "opt/v" and "<model>/<module path>/<leaf>".
         """
         tmp_path = path + ".tmp"
         c, f, bg = self._slices(self.flat)
-        blob = dict(format="lnrf-params-v2",
-                    coarse=_tree_to_host(self.state.params["coarse"]),
-                    fine=_tree_to_host(self.state.params["fine"]),
-                    background=bg.detach().cpu().numpy(),
-                    opt_state=dict(step=self.state.step, m=self.state.opt_m.detach().cpu().numpy(),
-                                   v=self.state.opt_v.detach().cpu().numpy()))
+        arrays = {"format": np.array("lnrf-params-v3"), "background": bg.detach().cpu().numpy(),
+                  "opt/step": np.array(self.state.step, dtype=np.int64),
+                  "opt/m": self.state.opt_m.detach().cpu().numpy(), "opt/v": self.state.opt_v.detach().cpu().numpy()}
+        for name in ("coarse", "fine"):
+            for key, leaf in _flatten_tree(self.state.params[name]):
+                arrays[f"{name}/{key}"] = leaf.detach().cpu().numpy()
         with open(tmp_path, "wb") as fh:
-            pickle.dump(blob, fh)
+            np.savez(fh, **arrays)
         os.rename(tmp_path, path)
 
     def load(self, path: str, load_optimizer: bool = True):
         """Load parameters (and, when present, the optimiser state) from a file written by save()."""
-        with open(path, "rb") as fh:
-            blob = pickle.load(fh)
-        c, f, bg = self._slices(self.flat)
-        c.copy_(_tree_from_host(blob["coarse"], self.coarse).to(self.device))
-        f.copy_(_tree_from_host(blob["fine"], self.fine).to(self.device))
-        bg.copy_(torch.as_tensor(blob["background"], dtype=F32).to(self.device))
-        opt = blob.get("opt_state")
-        if load_optimizer and opt is not None and opt["m"].shape[0] == self.flat.numel():
-            self.state.opt_m.copy_(torch.as_tensor(opt["m"], dtype=F32).to(self.device))
-            self.state.opt_v.copy_(torch.as_tensor(opt["v"], dtype=F32).to(self.device))
-            self.state.step = int(opt["step"])
+        with np.load(path, allow_pickle=False) as blob:
+            if str(blob["format"]) != "lnrf-params-v3":
+                raise ValueError(f"{path}: not an lnrf-params-v3 checkpoint")
+            c, f, bg = self._slices(self.flat)
+            for name, model, dst in (("coarse", self.coarse, c), ("fine", self.fine, f)):
+                leaves = [torch.from_numpy(blob[f"{name}/{module}/{leaf}"]).to(F32).reshape(-1)
+                          for module, leaf, _ in model.param_spec()]
+                dst.copy_(torch.cat(leaves).to(self.device))
+            bg.copy_(torch.from_numpy(blob["background"]).to(F32).to(self.device))
+            if load_optimizer and "opt/m" in blob and blob["opt/m"].shape[0] == self.flat.numel():
+                self.state.opt_m.copy_(torch.from_numpy(blob["opt/m"]).to(self.device))
+                self.state.opt_v.copy_(torch.from_numpy(blob["opt/v"]).to(self.device))
+                self.state.step = int(blob["opt/step"])
         self._params_changed()
 
     # ---- the step --------------------------------------------------------------------------------
@@ -228,21 +233,11 @@ class TrainLoop:
 
     def _step(self, key, bmin, bmax, batch):
         self.grad.zero_()
-        loss_dict, world = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
-        if _dist() is not None:  # also with a single rank: keeps the collective path exercised
-            with _prof.section("allreduce"):
-                parallel.all_reduce_sum_(self.grad)  # RCCL sum over ranks; averaged by grad_scale below
-        scale = 1.0 / world
-        with _prof.section("norms_adam"):
-            norms = torch.zeros(2, dtype=F32, device=self.device)
-            ops.sq_norm_into(self.grad, norms[0:1])
-            ops.sq_norm_into(self.flat, norms[1:2])
-            self.state.step += 1
-            ops.adam_step_(self.flat, self.grad, self.state.opt_m, self.state.opt_v, self.lr, self.adam_b1,
-                           self.adam_b2, self.adam_eps, self.state.step, grad_scale=scale)
-            self._params_changed()
-        loss_dict["grad_norm"] = torch.sqrt(norms[0]) * scale  # train.py:99-104
-        loss_dict["param_norm"] = torch.sqrt(norms[1])
+        loss_dict, _ = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
+        self.state.step += 1
+        loss_dict.update(apply_gradients(self.flat, self.grad, self.state.opt_m, self.state.opt_v, self.state.step,
+                                         self.lr, self.adam_b1, self.adam_b2, self.adam_eps))
+        self._params_changed()
         return loss_dict
 
     def losses(self, key: KeyLike, bbox_min, bbox_max, batch: torch.Tensor, params=None):
@@ -274,17 +269,51 @@ class TrainLoop:
         return self._average_density(key, model, model.flat(params), _vec3(bbox_min), _vec3(bbox_max), None)
 
 
-def _tree_to_host(tree):
-    if isinstance(tree, torch.Tensor):
-        return tree.detach().cpu().numpy()
-    return {k: _tree_to_host(v) for k, v in tree.items()}
+def apply_gradients(flat, grad, opt_m, opt_v, step: int, lr: float, b1: float, b2: float, eps: float,
+                    kernels=ops) -> Dict[str, torch.Tensor]:
+    """
+    What follows jax.grad in the reference's step (train.py:99-106), in its data-parallel form:
+      1. ONE all-reduce (sum) of the flat gradient over the process group (parallel.reduce_gradient_),
+      2. grad_norm / param_norm of the REDUCED gradient and of the parameters before the update (train.py:99-104);
+         the mean over ranks is the factor 1/world applied to the logged grad_norm ...
+      3. ... and inside the fused Adam kernel (grad_scale), optax.adam as at train.py:59.
+    `kernels` supplies sq_norm_into(x, out) and adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=...):
+    learn_nerf.ops (HIP) in the product; tests/test_dp_gloo.py passes a CPU implementation to drive this same
+    sequence under gloo.  Returns {"grad_norm", "param_norm"}.
+    """
+    with _prof.section("allreduce"):
+        scale = parallel.reduce_gradient_(grad)
+    with _prof.section("norms_adam"):
+        norms = torch.zeros(2, dtype=F32, device=flat.device)
+        kernels.sq_norm_into(grad, norms[0:1])
+        kernels.sq_norm_into(flat, norms[1:2])
+        kernels.adam_step_(flat, grad, opt_m, opt_v, lr, b1, b2, eps, step, grad_scale=scale)
+    return dict(grad_norm=torch.sqrt(norms[0]) * scale, param_norm=torch.sqrt(norms[1]))
 
 
-def _tree_from_host(tree, model: ModelBase) -> torch.Tensor:
-    from .params import leaves_in_order
+def load_params(path: str, coarse: ModelBase, fine: ModelBase, device) -> Dict[str, Any]:
+    """The params tree {"coarse", "fine", "background"} of a checkpoint written by TrainLoop.save, on `device`
+    (what scripts/render_nerf.py:56-58 gets from pickle.load in the reference)."""
+    out = {}
+    with np.load(path, allow_pickle=False) as blob:
+        if str(blob["format"]) != "lnrf-params-v3":
+            raise ValueError(f"{path}: not an lnrf-params-v3 checkpoint")
+        for name, model in (("coarse", coarse), ("fine", fine)):
+            leaves = [torch.from_numpy(blob[f"{name}/{module}/{leaf}"]).to(F32).reshape(-1)
+                      for module, leaf, _ in model.param_spec()]
+            out[name] = model.tree(torch.cat(leaves).to(device))
+        out["background"] = torch.from_numpy(blob["background"]).to(F32).to(device)
+    return out
 
-    leaves = leaves_in_order(tree, model.param_spec())
-    return torch.cat([torch.as_tensor(l, dtype=F32).reshape(-1) for l in leaves])
+
+def _flatten_tree(tree, prefix=""):
+    """(path, leaf) pairs of a nested parameter dict, '/'-joined paths."""
+    for k, v in tree.items():
+        path = f"{prefix}/{k}" if prefix else k
+        if isinstance(v, torch.Tensor):
+            yield path, v
+        else:
+            yield from _flatten_tree(v, path)
 
 
 def default_loss_weights() -> Dict[str, float]:

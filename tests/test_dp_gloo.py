@@ -97,6 +97,127 @@ def test_two_rank_gradient_equals_global_batch(tmp_path):
     assert torch.allclose(g0, full, rtol=1e-9, atol=1e-12)
 
 
+class CpuKernels:
+    """CPU stand-in for the two HIP kernel families TrainLoop's update uses (ops.sq_norm_into, ops.adam_step_),
+    with the oracle's Adam (oracle/train.py) — so that train.apply_gradients, the PRODUCT's reduce -> 1/W ->
+    norms -> Adam sequence, can run on CPU tensors under gloo."""
+
+    @staticmethod
+    def sq_norm_into(x, out):
+        out.copy_((x.double() ** 2).sum().reshape(1).to(out.dtype))
+
+    @staticmethod
+    def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+        from oracle import train as OT
+
+        p2, m2, v2 = OT.adam_update(p.double(), g.double() * grad_scale, m.double(), v.double(), step, lr, b1, b2, eps)
+        p.copy_(p2.to(p.dtype))
+        m.copy_(m2.to(m.dtype))
+        v.copy_(v2.to(v.dtype))
+
+
+def _update_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from learn_nerf import parallel
+    from learn_nerf.train import apply_gradients
+
+    parallel.init_distributed(backend="gloo")
+    cf, ff = _params()
+    flat = torch.cat([cf, ff, torch.tensor([-1.0, -1.0, -1.0], dtype=F64)]).float()
+    shard, offset = parallel.shard_rays(_batch(), rank, world)
+    grad = _grad(shard, offset).float()  # this rank's gradient of ITS shard's mean loss
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    logs = []
+    for step in (1, 2):  # two steps: the second one sees non-zero moments
+        g = grad.clone() * (1.0 if step == 1 else 0.5)
+        log = apply_gradients(flat, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7, kernels=CpuKernels)
+        logs.append({k: float(x) for k, x in log.items()})
+    torch.save(dict(flat=flat, m=m, v=v, logs=logs), os.path.join(out_dir, f"u{rank}.pt"))
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_product_update_equals_global_batch_step(tmp_path):
+    """train.apply_gradients (what TrainLoop._step runs after the backward) under gloo, world_size 2:
+    all-reduce(sum) -> grad_norm * 1/W -> Adam with grad_scale 1/W  ==  the single-process step on the
+    global batch (train.py:99-106)."""
+    from oracle import train as OT
+
+    world = 2
+    mp.spawn(_update_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "u0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "u1.pt"))
+    for k in ("flat", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), f"ranks disagree on {k} after the update"
+    assert r0["logs"] == r1["logs"]
+    # single process, global batch
+    cf, ff = _params()
+    p = torch.cat([cf, ff, torch.tensor([-1.0, -1.0, -1.0], dtype=F64)]).float().double()
+    full = _grad(_batch(), 0).float().double()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step, logs in zip((1, 2), r0["logs"]):
+        g = full * (1.0 if step == 1 else 0.5)
+        assert abs(logs["grad_norm"] - float(g.norm())) < 1e-5 * float(g.norm())
+        assert abs(logs["param_norm"] - float(p.norm())) < 1e-5 * float(p.norm())
+        p, m, v = OT.adam_update(p, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7)
+    # fp32 state on the ranks vs float64 here: Adam normalises steps to ~lr, so compare at a fraction of lr
+    assert (r0["flat"].double() - p).abs().max().item() < 2e-5
+    assert torch.allclose(r0["m"].double(), m, rtol=1e-4, atol=1e-9)
+
+
+def _shuffle_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import numpy as np
+
+    from learn_nerf import parallel
+    from learn_nerf.dataset import ModelMetadata, NeRFDataset, NeRFView
+
+    class View(NeRFView):
+        def __init__(self, img, **kw):
+            super().__init__(**kw)
+            self._img = img
+
+        def image(self):
+            return self._img
+
+    rng = np.random.default_rng(0)
+    views = [View((rng.random((40, 40, 3)) * 255).astype(np.uint8), camera_direction=(0.0, 1.0, 0.0),
+                  camera_origin=(float(i), 2.0, 2.0), x_axis=(-1.0, 0.0, 0.0), y_axis=(0.0, 0.0, 1.0), x_fov=1.0,
+                  y_fov=1.0) for i in range(6)]
+    parallel.init_distributed(backend="gloo")
+    ds = NeRFDataset(metadata=ModelMetadata((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), views=views)
+    it = ds.iterate_batches(os.path.join(out_dir, "shuffled"), 77, batch_size=333, repeat=True)
+    got = torch.stack([next(it) for _ in range(40)])  # 40 x 333 rays: more than one epoch of 9600
+    torch.save(got, os.path.join(out_dir, f"b{rank}.pt"))
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_a_fresh_shuffle_dir(tmp_path):
+    """on a fresh dataset every rank used to truncate and rewrite the same 32 shard files.  Now rank 0
+    alone deals the rays (temporary names, renamed, marker last) and the others wait: both ranks must read
+    identical, complete batches from an initially EMPTY shuffle directory."""
+    world = 2
+    mp.spawn(_shuffle_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    b0 = torch.load(os.path.join(tmp_path, "b0.pt"))
+    b1 = torch.load(os.path.join(tmp_path, "b1.pt"))
+    assert torch.equal(b0, b1)
+    first_epoch = b0.reshape(-1, 9)[:9600]
+    assert len({tuple(r.tolist()) for r in first_epoch}) == 9600, "an epoch visits every ray exactly once"
+    names = sorted(os.listdir(tmp_path / "shuffled"))
+    assert len(names) == 33 and not any(n.endswith(".tmp") for n in names)
+
+
 def test_shard_bounds_and_errors():
     from learn_nerf import parallel
 

@@ -34,6 +34,34 @@ def test_sh_and_ide_kernels(deg):
     assert (ide.cpu().double() - ORF.integrated_directional_encoding(deg, v.double(), r.double())).abs().max().item() < 2e-5
 
 
+def test_ide_kernel_matches_reference_polynomial_table():
+    """lnrf_integrated_directional_encoding against the reference's own 64-polynomial table (ref_nerf.py:174-311)
+    evaluated at fixed unit vectors (tests/golden/sh_table_v1.npz): all degrees, all basis functions, and the
+    exp(-rho l (l + 1) / 2) attenuation (ref_nerf.py:121-143)."""
+    import os
+
+    import numpy as np
+
+    from learn_nerf.ref_nerf import integrated_directional_encoding, spherical_harmonic
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sh_table_v1.npz"))
+    dirs = torch.from_numpy(g["dirs"]).float().contiguous()
+    # the fixture's directions rounded to fp32 are no longer exactly unit: re-evaluate nothing, just bound the
+    # effect (polynomials of degree <= 7, coefficients <= ~10: |d value| < 1e-5)
+    levels = np.concatenate([[l] * (2 * l + 1) for l in range(8)])
+    rho = torch.linspace(0.0, 1.5, dirs.shape[0])[:, None].contiguous()
+    for degree in range(1, 9):
+        n = degree * degree
+        sh = spherical_harmonic(degree, dirs.cuda()).cpu().double().numpy()
+        assert sh.shape == (14, n)
+        err = np.abs(sh - g["values"][:, :n]).max()
+        ide = integrated_directional_encoding(degree, dirs.cuda(), rho.cuda()).cpu().double().numpy()
+        want = g["values"][:, :n] * np.exp(-rho.double().numpy() * levels[:n] * (levels[:n] + 1) / 2)
+        err_ide = np.abs(ide - want).max()
+        print(f"degree {degree}: max |SH - reference table| {err:.2e}, IDE {err_ide:.2e}")
+        assert err < 2e-5 and err_ide < 2e-5
+
+
 def make_model(seed=3, precision="fp32", **kw):
     from learn_nerf.ref_nerf import RefNERFModel
 

@@ -24,6 +24,29 @@ def test_sh_constants_on_z_axis():  # ref_nerf.py:174-186
     assert abs(out[1]) < 1e-15 and abs(out[3]) < 1e-15
 
 
+def test_sh_matches_reference_polynomial_table():
+    """The one numeric table the reference holds on this path: all 64 polynomials of ref_nerf.py:174-311, evaluated
+    from the reference's coefficients (tests/golden/make_sh_table_golden.py) at 14 fixed unit vectors.  This PINS
+    the oracle's spherical harmonics (Legendre-recurrence restatement) for every degree, incl. the +-m pairing."""
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sh_table_v1.npz"))
+    dirs = torch.from_numpy(g["dirs"])
+    assert g["values"].shape == (14, 64) and np.allclose(np.linalg.norm(g["dirs"], axis=1), 1.0)
+    for degree in range(1, 9):
+        got = ORF.spherical_harmonic(degree, dirs).numpy()
+        assert got.shape == (14, degree * degree)
+        err = np.abs(got - g["values"][:, :degree * degree]).max()
+        assert err < 1e-13, (degree, err)
+    # integrated directional encoding: the same values attenuated per level l by exp(-rho l (l + 1) / 2)
+    rho = torch.linspace(0.0, 1.5, 14, dtype=F64)[:, None]
+    ide = ORF.integrated_directional_encoding(8, dirs, rho).numpy()
+    levels = np.concatenate([[l] * (2 * l + 1) for l in range(8)])
+    assert np.abs(ide - g["values"] * np.exp(-rho.numpy() * levels * (levels + 1) / 2)).max() < 1e-13
+
+
 def test_sh_low_degree_closed_forms():
     v = unit(20)
     x, y, z = v[:, 0], v[:, 1], v[:, 2]
