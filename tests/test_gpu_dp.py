@@ -53,8 +53,9 @@ def test_two_rank_train_step_equals_global_batch_step(tmp_path):
     single = _run(1, str(tmp_path))[0]
     r0, r1 = _run(2, str(tmp_path))
     assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["m"], r1["m"]), "ranks diverged"
-    for a, b in zip(r0["logs"], r1["logs"]):
-        assert a["grad_norm"] == b["grad_norm"] and a["param_norm"] == b["param_norm"]
+    for a, b in zip(r0["logs"], r1["logs"]):  # the norm kernel combines per-block partial sums by fp32 atomics
+        assert abs(a["grad_norm"] - b["grad_norm"]) < 1e-6 * a["grad_norm"]
+        assert abs(a["param_norm"] - b["param_norm"]) < 1e-6 * a["param_norm"]
     for it, (dp, ref) in enumerate(zip(r0["logs"], single["logs"])):
         print(f"step {it}: grad_norm dp {dp['grad_norm']:.6f} single {ref['grad_norm']:.6f}; "
               f"rank-0 shard loss {dp['fine']:.5f}, global loss {ref['fine']:.5f}")
