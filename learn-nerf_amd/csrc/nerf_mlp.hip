@@ -9,7 +9,7 @@
 //            gradients dy_l and dumps them, (2) a split-K MFMA kernel reduces
 //            dW_l = X_l^T dy_l over all evaluations from the forward/backward dumps.
 // Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / positional encoding.
-#include "fused_chain.h"
+#include "nerf_chain.h"
 
 namespace lnrf {
 
@@ -21,10 +21,6 @@ __device__ unsigned long long* g_timeline_buf = nullptr;  // 3 kernels x 8 waves
 struct FwdSeq {
   static constexpr int count = kFwdUsed;
   static constexpr int at(int c) { return fwd_seq(c); }
-};
-struct BwdSeq {
-  static constexpr int count = kBwdUsed;
-  static constexpr int at(int c) { return bwd_seq(c); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -418,10 +414,8 @@ __global__ __launch_bounds__(kSplitThreads) void nerf_fwd_split_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward, part 1: input-gradient chain.  Produces dy_l (pre-activation gradients) dumps.
+// Backward, part 1: input-gradient chain (nerf_chain.h).  Produces dy_l (pre-activation gradients) dumps.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBwdStages = kBwdFrags / kStageFrags;  // 70
-
 __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
     const char* __restrict__ packed, const char* __restrict__ save, const float* __restrict__ density,
     const float* __restrict__ rgb, const float* __restrict__ g_density, const float* __restrict__ g_rgb,
@@ -429,28 +423,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
-  const int64_t m = tile * kTileCols + c;
-  const bool valid = m < M;
-
-  // head gradients (fp32): d/d(pre-tanh) and d/d(density logit)
-  float gy11[3] = {0, 0, 0}, gy9 = 0.0f;
-  if (valid && h == 0) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float y = rgb[m * 3 + k];
-      gy11[k] = g_rgb[m * 3 + k] * (1.0f - y * y);             // tanh'
-    }
-    gy9 = g_density[m] * -expm1f(-density[m]);                // softplus' = sigmoid = 1 - exp(-sp), no cancellation
-  }
-  // ReLU masks of h0..h7 and h10 (written by the forward), 16 bytes per lane and layer
-  uint4 relu_mask[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i)
-    relu_mask[i] = *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) * kFragBytes +
-                                                   lane * 16);
-  __syncthreads();
 
   Ring<kBwdStages, BwdSeq> ring;
   ring.stream = packed + kPackBwdOff;
@@ -462,82 +435,8 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   ring.tl.on = g_timeline_buf != nullptr && blockIdx.x == gridDim.x / 2;
   ring.tl.stamp();
 #endif
-  ring.prologue();
-  LNRF_TL_STAMP(ring);
-
-  DumpAddr gd{gdump, n_tiles, tile, c, h};
-  auto dump_frag = [&](int slot, const bf16x8& f) {
-    stream_store(gd.at(slot), frag_to_bits(f));
-  };
-
-  bf16x8 a0[16], a1[16];
-
-  // dy11 fragment: k slot (h=0, j<3) = rgb channel
-  bf16x8 dy11 = zero_frag();
-  dy11[0] = (__bf16)gy11[0];
-  dy11[1] = (__bf16)gy11[1];
-  dy11[2] = (__bf16)gy11[2];
-  dump_frag(kGradDy11, dy11);
-  dump_frag(kGradDy11 + 1, zero_frag());
-
-  // T0: Dense_11^T -> dh10, masked by relu(h10)
-  chain_layer<bwd_cons_base(0), bwd_nk(0), bwd_no(0)>(
-      ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy11; },
-      [&](auto o_, const f32x16& acc) {
-        constexpr int o = decltype(o_)::value;
-        const unsigned mb = (o >> 1) == 0 ? relu_mask[8].x : relu_mask[8].y;
-        a0[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
-        a0[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
-        dump_frag(kGradDy10m + 2 * o, a0[2 * o]);
-        dump_frag(kGradDy10m + 2 * o + 1, a0[2 * o + 1]);
-      });
-  // logit-gradient fragment: slot (h=0, j=0)
-  bf16x8 dlogit = zero_frag();
-  dlogit[0] = (__bf16)gy9;
-  dump_frag(kGradDy10m + 8, dlogit);
-  dump_frag(kGradDy10m + 9, zero_frag());
-
-  // T1: [Dense_10 | Dense_9]^T (z rows) -> dz = dy8 (Dense_8 output is linear)
-  chain_layer<bwd_cons_base(1), bwd_nk(1), bwd_no(1)>(
-      ring, [&](auto) { return zero_acc(); },
-      [&](auto k_) -> bf16x8 {
-        constexpr int ks = decltype(k_)::value;
-        if constexpr (ks < 8) return a0[ks];
-        else return dlogit;
-      },
-      [&](auto o_, const f32x16& acc) {
-        constexpr int o = decltype(o_)::value;
-        a1[2 * o] = acc_to_frag<0, false>(acc);
-        a1[2 * o + 1] = acc_to_frag<1, false>(acc);
-        dump_frag(grad_dy_slot(8) + 2 * o, a1[2 * o]);
-        dump_frag(grad_dy_slot(8) + 2 * o + 1, a1[2 * o + 1]);
-      });
-
-  // T2..T9: Dense_l^T for l = 8..1: dy_l (in) -> dh_{l-1}, masked by relu(h_{l-1}) -> dy_{l-1}
-  auto back = [&](auto t_, bf16x8(&in)[16], bf16x8(&out)[16]) {
-    constexpr int TT = decltype(t_)::value;
-    constexpr int l = bwd_dense(TT);  // dense layer whose transpose is applied
-    chain_layer<bwd_cons_base(TT), bwd_nk(TT), bwd_no(TT)>(
-        ring, [&](auto) { return zero_acc(); },
-        [&](auto k_) -> bf16x8 { return in[decltype(k_)::value]; },
-        [&](auto o_, const f32x16& acc) {
-          constexpr int o = decltype(o_)::value;
-          const uint4 mk = relu_mask[l - 1];
-          const unsigned mb = (o >> 1) == 0 ? mk.x : ((o >> 1) == 1 ? mk.y : ((o >> 1) == 2 ? mk.z : mk.w));
-          out[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
-          out[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
-          dump_frag(grad_dy_slot(l - 1) + 2 * o, out[2 * o]);
-          dump_frag(grad_dy_slot(l - 1) + 2 * o + 1, out[2 * o + 1]);
-        });
-  };
-  back(std::integral_constant<int, 2>{}, a1, a0);  // Dense_8^T: dy8 -> dy7
-  back(std::integral_constant<int, 3>{}, a0, a1);  // dy7 -> dy6
-  back(std::integral_constant<int, 4>{}, a1, a0);  // dy6 -> dy5
-  back(std::integral_constant<int, 5>{}, a0, a1);  // Dense_5^T (h rows): dy5 -> dy4
-  back(std::integral_constant<int, 6>{}, a1, a0);  // dy4 -> dy3
-  back(std::integral_constant<int, 7>{}, a0, a1);  // dy3 -> dy2
-  back(std::integral_constant<int, 8>{}, a1, a0);  // dy2 -> dy1
-  back(std::integral_constant<int, 9>{}, a0, a1);  // Dense_1^T: dy1 -> dy0
+  GlobalDumpSink sink{DumpAddr{gdump, n_tiles, tile, lane & 31, lane >> 5}};
+  bwd_chain_tile(ring, sink, save, n_tiles, density, rgb, g_density, g_rgb, M, tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,52 +447,6 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
 // every wave reads its operand tiles transposed (ds_read_b64_tr_b16: feature on the lane,
 // evaluation in the registers) for the 32x32x16 MFMA.  Partial sums leave by fp32 atomics.
 // ---------------------------------------------------------------------------------------------
-enum { ROW_HIDDEN = 0, ROW_XEMB = 1, ROW_DEMB = 2 };
-enum { COL_256 = 0, COL_DY10M = 1, COL_DY11 = 2 };
-struct WgradProblem {
-  int shape;     // operand-shape body, see nerf_wgrad_kernel
-  int x_slot0;   // first X slot in the forward save buffer
-  int y_slot0;   // first dy slot in the gradient dump
-  int dense;     // Flax Dense index (COL_DY10M: Dense_10 with Dense_9 attached as column 128)
-  int row_map;   // how X slots map to kernel rows
-  int row_off;   // first kernel row of this block
-  int col_map;
-  int do_bias;
-  int first_block, n_blocks;
-};
-constexpr int kMaxProblems = 13;
-struct WgradArgs {
-  WgradProblem p[kMaxProblems];
-  int n_problems;
-};
-
-// NeRFModel gradient-vector addressing for the shared weight-gradient body
-struct NerfWgradEpi {
-  static __device__ __forceinline__ void cols(const WgradProblem& pb, int ot, int colr, int& out_idx, int& out_dim,
-                                              int64_t& w_off, int64_t& b_off) {
-    int dense_w = pb.dense;
-    if (pb.col_map == COL_DY10M) {  // tiles 0..3 = Dense_10 outputs, tile 4 column 0 = Dense_9
-      if (ot < 4) { out_idx = 32 * ot + colr; out_dim = 128; dense_w = 10; }
-      else if (colr == 0 && pb.row_map == ROW_HIDDEN) { out_idx = 0; out_dim = 1; dense_w = 9; }
-    } else if (pb.col_map == COL_DY11) {
-      if (colr < 3) { out_idx = colr; out_dim = 3; }
-    } else {
-      out_idx = 32 * ot + colr; out_dim = 256;
-    }
-    w_off = dense_w_off(dense_w);
-    b_off = dense_b_off(dense_w);
-  }
-  static __device__ __forceinline__ int row(const WgradProblem& pb, int f, int r16) {
-    const int sh = (r16 >> 2) & 1, sj = 4 * (r16 >> 3) + (r16 & 3);  // slot (h, j) of that feature
-    int in_idx;
-    if (pb.row_map == ROW_HIDDEN) in_idx = 16 * f + r16;
-    else if (pb.row_map == ROW_XEMB) in_idx = xemb_feat(f, sh, sj);
-    else in_idx = demb_feat(f, sh, sj);
-    return in_idx >= 0 ? in_idx + pb.row_off : -1;
-  }
-};
-
-
 // One launch for every Dense layer of the model: blockIdx -> problem -> operand-shape body.
 // Problems are listed heaviest first so that the small ones fill the tail of the launch.
 __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, const char* __restrict__ save,
@@ -689,14 +542,8 @@ __global__ void nerf_pack_split_kernel(const float* __restrict__ params, char* _
 
 using namespace lnrf;
 
-static bool shape_supported(const lnrf_nerf_shape* s) {
-  return s && s->input_layers == 5 && s->mid_layers == 4 && s->hidden_dim == 256 &&
-         s->color_layer_dim == 128 && s->x_freqs == 10 && s->d_freqs == 4;
-}
-// Tiles are padded to whole workgroups (8 waves): every wave then owns a dump slot, so the dump stores need no
-// branch — a conditional store makes hipcc lose count of the outstanding VMEM operations and wait vmcnt(0) (= drain all
-// dump stores) before every ring write.  Padding tiles hold finite activations and zero gradients.
-static inline int64_t tiles_for(int64_t m) { return ((m + kTileCols - 1) / kTileCols + kWaves - 1) / kWaves * kWaves; }
+static bool shape_supported(const lnrf_nerf_shape* s) { return nerf_shape_fused(s); }
+static inline int64_t tiles_for(int64_t m) { return nerf_tiles_for(m); }
 
 extern "C" int64_t lnrf_nerf_param_count(const lnrf_nerf_shape* s) {
   if (!s) return -1;
@@ -866,34 +713,10 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   const int64_t n_tiles = tiles_for(m);
   hipStream_t st = as_stream(stream);
   int rc;
-  // weight-gradient problems: ONE launch, heaviest problems first
+  // weight-gradient problems: ONE launch, heaviest problems first, blocks proportional to bytes
   WgradArgs a;
-  a.n_problems = 0;
-  int first = 0;
-  auto add = [&](int shape, int xs, int ys, int dense, int row_map, int row_off, int col_map, int do_bias,
-                 int blocks) {
-    WgradProblem p;
-    p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
-    p.col_map = col_map; p.do_bias = do_bias;
-    int64_t nb = blocks;
-    const int64_t max_nb = (n_tiles + 5) / 6;
-    if (nb > max_nb) nb = max_nb;
-    p.first_block = first;
-    p.n_blocks = (int)nb;
-    first += (int)nb;
-    a.p[a.n_problems++] = p;
-  };
-  // hidden x hidden: Dense_1..8 (Dense_5: rows 0..255)
-  for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, COL_256, 1, l <= 4 ? 48 : 47);
-  // z x dy10m: Dense_10 rows 0..255 and Dense_9
-  add(1, kSaveZ, kGradDy10m, 10, ROW_HIDDEN, 0, COL_DY10M, 1, 39);
-  // x_emb x dy0 (Dense_0) and x_emb x dy5 (Dense_5 rows 256..315)
-  add(2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_256, 1, 30);
-  add(2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, COL_256, 0, 30);
-  // d_emb x dy10m: Dense_10 rows 256..279
-  add(3, kSaveDin, kGradDy10m, 10, ROW_DEMB, 256, COL_DY10M, 0, 18);
-  // h10 x dy11: Dense_11
-  add(4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1, 15);
+  const int blocks[13] = {48, 48, 48, 48, 47, 47, 47, 47, 39, 30, 30, 18, 15};
+  const int first = build_wgrad_problems(a, blocks, (n_tiles + 5) / 6);
   const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
   rc = ensure_lds(nerf_wgrad_kernel, lds);
   if (rc) return rc;

@@ -13,6 +13,7 @@ Arrays are torch tensors on the GPU.  NeRFModel has two compute paths, both hand
   precision="fp32": exact-fp32 dense kernels on the f32 MFMA (dense.hip) — parity/any shape.
 """
 import ctypes
+import os
 import warnings
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -86,6 +87,27 @@ class ModelBase:
         raise NotImplementedError
 
 
+_FUSED_WS = {}
+
+
+def _fused_bwd_workspace(shape, device) -> torch.Tensor:
+    """One workspace per device for lnrf_nerf_mlp_bwd_fused (control words + Infinity-Cache-resident rings); calls on
+    one stream may share it.  fused_bwd_status() reads its status word."""
+    key = (device.type, device.index)
+    if key not in _FUSED_WS:
+        nbytes = L.lib().lnrf_nerf_bwd_fused_workspace_bytes(ctypes.byref(shape))
+        _FUSED_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return _FUSED_WS[key]
+
+
+def fused_bwd_status(device=None) -> int:
+    """Status word of the last lnrf_nerf_mlp_bwd_fused launch on `device` (synchronises): 0 = every hand-off completed;
+    otherwise the code of the bounded wait that gave up (gradients of that call are invalid)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _FUSED_WS.get((device.type, device.index))
+    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
+
+
 def _is_leafy(d) -> bool:
     return any(isinstance(v, torch.Tensor) for v in d.values())
 
@@ -116,6 +138,9 @@ class NeRFModel(ModelBase):
     d_freqs: int = 4
     precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
     render_precision: str = "bf16x3"  # fused path, forward without backward: "bf16x3" (split) | "bf16"
+    # fused path, backward: "fused" = one persistent launch (chain + weight gradients, lnrf_nerf_mlp_bwd_fused) |
+    # "split" = separate chain and weight-gradient launches through HBM (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
+    backward_kernel: str = os.environ.get("LNRF_NERF_BACKWARD", "split")
     tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
 
     _pack_cache: Any = field(default=None, repr=False, compare=False)
@@ -264,9 +289,19 @@ class NeRFModel(ModelBase):
         if ctx["kind"] == "fused":
             shape = self._shape_struct()
             m = ctx["m"]
+            tag = ctx.get("tag", "mlp")
+            if self.backward_kernel == "fused":
+                ws = _fused_bwd_workspace(shape, grad_flat.device)
+                with _prof.section(f"{tag}_bwd_fused"):
+                    rc = L.lib().lnrf_nerf_mlp_bwd_fused(
+                        ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
+                        L.ptr(ctx["density"]), L.ptr(ctx["rgb"]), L.ptr(g_density.reshape(-1)),
+                        L.ptr(g_rgb.reshape(-1, 3)), m, L.ptr(ws, torch.uint8), L.ptr(grad_flat), L.stream())
+                if rc != L.ERR_UNSUPPORTED:
+                    L.check(rc, "nerf_mlp_bwd_fused")
+                    return
             nbytes = L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=grad_flat.device)
-            tag = ctx.get("tag", "mlp")
             with _prof.section(f"{tag}_bwd_chain"):
                 L.check(L.lib().lnrf_nerf_mlp_bwd_chain(
                     ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
