@@ -412,6 +412,19 @@ int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const fl
 int lnrf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                    float b2, float eps, int32_t step, float grad_scale, lnrf_stream_t stream);
 
+/* lnrf_adam_step that also accumulates the two tree_norm numerators of the step's log (train.py:92-104) while it
+ * streams the buffers: sq_norms[0] += sum g^2 (g as passed in, i.e. the all-reduced SUM; multiply the root by
+ * grad_scale), sq_norms[1] += sum p^2 of the parameters BEFORE the update.  sq_norms: 2 floats, zeroed by the caller. */
+int lnrf_adam_step_norms(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                         float b2, float eps, int32_t step, float grad_scale, float* sq_norms,
+                         lnrf_stream_t stream);
+
+/* The scalar log of one step (train.py:141-144: mean squared errors; train.py:99-104: norms) from its accumulators:
+ * sums = [sum sq err coarse, sum sq err fine, sum g^2, sum p^2] -> out = [sums[0] * inv_count, sums[1] * inv_count,
+ * sqrt(sums[2]) * grad_scale, sqrt(sums[3])]; clear != 0 zeroes sums afterwards (ready for the next step). */
+int lnrf_step_log(float* sums, float inv_count, float grad_scale, int32_t clear, float* out,
+                  lnrf_stream_t stream);
+
 /* *out += sum x^2 (tree_norm numerator, train.py:92-97). out must be zeroed by the caller. */
 int lnrf_sq_norm(const float* x, int64_t n, float* out, lnrf_stream_t stream);
 

@@ -113,6 +113,9 @@ PROTOTYPES = {
     "lnrf_comm_destroy": (c_int32, [_P]),
     "lnrf_adam_step": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
                                  c_float, _P]),
+    "lnrf_adam_step_norms": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
+                                       c_float, _P, _P]),
+    "lnrf_step_log": (c_int32, [_P, c_float, c_float, c_int32, _P, _P]),
     "lnrf_sq_norm": (c_int32, [_P, c_int64, _P, _P]),
 }
 

@@ -398,9 +398,23 @@ def refnerf_color_bwd(dir_out, spectral, diffuse, g_rgb):
 
 # ---------------------------------------------------------------- optimiser
 
-def adam_step_(p, g, m, v, lr, b1, b2, eps, step: int, grad_scale: float = 1.0):
-    L.check(L.lib().lnrf_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, step,
-                                   grad_scale, L.stream()), "adam_step")
+def adam_step_(p, g, m, v, lr, b1, b2, eps, step: int, grad_scale: float = 1.0, sq_norms=None):
+    """Fused Adam over flat buffers; with sq_norms (2 floats, pre-zeroed) the same pass accumulates sum g^2 (g as
+    passed in) and sum p^2 (before the update) for the step's log."""
+    if sq_norms is None:
+        L.check(L.lib().lnrf_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, step,
+                                       grad_scale, L.stream()), "adam_step")
+    else:
+        L.check(L.lib().lnrf_adam_step_norms(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, step,
+                                             grad_scale, L.ptr(sq_norms), L.stream()), "adam_step_norms")
+
+
+def step_log(sums: torch.Tensor, inv_count: float, grad_scale: float, clear: bool = True) -> torch.Tensor:
+    """[sum sq err coarse, sum sq err fine, sum g^2, sum p^2] -> [coarse loss, fine loss, grad_norm, param_norm]."""
+    out = torch.empty(4, dtype=F32, device=_dev(sums))
+    L.check(L.lib().lnrf_step_log(L.ptr(sums), inv_count, grad_scale, 1 if clear else 0, L.ptr(out), L.stream()),
+            "step_log")
+    return out
 
 
 def sq_norm_into(x: torch.Tensor, out: torch.Tensor):

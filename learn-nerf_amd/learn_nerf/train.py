@@ -92,6 +92,7 @@ class TrainLoop:
         self.state = TrainState(params=self._views(self.flat), step=0, opt_m=torch.zeros_like(self.flat),
                                 opt_v=torch.zeros_like(self.flat))
         self._scalars = torch.zeros(8, dtype=F32, device=self.device)
+        self._scalars_dirty = False  # lnrf_step_log leaves the accumulators zeroed for the next step
 
     def _params_changed(self):
         # the kernels write through raw pointers, which torch's version counters do not see
@@ -163,8 +164,10 @@ class TrainLoop:
         dist = _dist()
         world = dist.get_world_size() if dist else 1
         c_flat, f_flat, bg = self._slices(params_flat)
-        sc = self._scalars
-        sc.zero_()
+        sc = self._scalars  # [sum sq err coarse, sum sq err fine, sum g^2, sum p^2, ...]: zero on entry
+        if self._scalars_dirty:
+            sc.zero_()
+        self._scalars_dirty = True
         render_key, density_key = split(key, 2)  # train.py:137
         coarse_key, fine_key = split(render_key, 2)  # render.py:55
         targets = batch[:, 2]
@@ -184,7 +187,8 @@ class TrainLoop:
                                                 targets=targets, sq_err=sc[1:2], want_coords=False)
 
         inv = 1.0 / (3.0 * n)
-        loss_dict = dict(coarse=sc[0] * inv, fine=sc[1] * inv)  # train.py:141-144
+        # train.py:141-144; in a training step the two means are produced by lnrf_step_log together with the norms
+        loss_dict = {} if want_grad else dict(coarse=sc[0] * inv, fine=sc[1] * inv)
         for prefix, names, asum in (("coarse", names_c, asum_c), ("fine", names_f, asum_f)):
             if names:
                 means = asum.mean(dim=0)
@@ -233,11 +237,17 @@ class TrainLoop:
 
     def _step(self, key, bmin, bmax, batch):
         self.grad.zero_()
-        loss_dict, _ = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
+        aux_losses, _ = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
         self.state.step += 1
-        loss_dict.update(apply_gradients(self.flat, self.grad, self.state.opt_m, self.state.opt_v, self.state.step,
-                                         self.lr, self.adam_b1, self.adam_b2, self.adam_eps))
+        sc = self._scalars
+        scale = apply_gradients(self.flat, self.grad, self.state.opt_m, self.state.opt_v, self.state.step, self.lr,
+                                self.adam_b1, self.adam_b2, self.adam_eps, sq_norms=sc[2:4])
+        log = ops.step_log(sc, 1.0 / (3.0 * batch.shape[0]), scale, clear=True)  # one launch; zeroes sc again
+        self._scalars_dirty = False
         self._params_changed()
+        loss_dict = dict(coarse=log[0], fine=log[1])  # train.py:141-144
+        loss_dict.update(aux_losses)
+        loss_dict.update(grad_norm=log[2], param_norm=log[3])  # train.py:99-104
         return loss_dict
 
     def losses(self, key: KeyLike, bbox_min, bbox_max, batch: torch.Tensor, params=None):
@@ -270,25 +280,23 @@ class TrainLoop:
 
 
 def apply_gradients(flat, grad, opt_m, opt_v, step: int, lr: float, b1: float, b2: float, eps: float,
-                    kernels=ops) -> Dict[str, torch.Tensor]:
+                    sq_norms: torch.Tensor, kernels=ops) -> float:
     """
     What follows jax.grad in the reference's step (train.py:99-106), in its data-parallel form:
       1. ONE all-reduce (sum) of the flat gradient over the process group (parallel.reduce_gradient_),
-      2. grad_norm / param_norm of the REDUCED gradient and of the parameters before the update (train.py:99-104);
-         the mean over ranks is the factor 1/world applied to the logged grad_norm ...
-      3. ... and inside the fused Adam kernel (grad_scale), optax.adam as at train.py:59.
-    `kernels` supplies sq_norm_into(x, out) and adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=...):
-    learn_nerf.ops (HIP) in the product; tests/test_dp_gloo.py passes a CPU implementation to drive this same
-    sequence under gloo.  Returns {"grad_norm", "param_norm"}.
+      2. optax.adam as at train.py:59 with the mean over ranks folded in as grad_scale = 1/world, and in the same
+         pass over the buffers
+      3. the tree_norm numerators (train.py:92-104) of the REDUCED gradient and of the parameters before the update:
+         sq_norms[0] += sum g^2 (of the summed gradient), sq_norms[1] += sum p^2.
+    Returns scale = 1/world: grad_norm = sqrt(sq_norms[0]) * scale, param_norm = sqrt(sq_norms[1]).
+    `kernels` supplies adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=..., sq_norms=...): learn_nerf.ops
+    (HIP) in the product; tests/test_dp_gloo.py passes a CPU implementation to drive this same sequence under gloo.
     """
     with _prof.section("allreduce"):
         scale = parallel.reduce_gradient_(grad)
     with _prof.section("norms_adam"):
-        norms = torch.zeros(2, dtype=F32, device=flat.device)
-        kernels.sq_norm_into(grad, norms[0:1])
-        kernels.sq_norm_into(flat, norms[1:2])
-        kernels.adam_step_(flat, grad, opt_m, opt_v, lr, b1, b2, eps, step, grad_scale=scale)
-    return dict(grad_norm=torch.sqrt(norms[0]) * scale, param_norm=torch.sqrt(norms[1]))
+        kernels.adam_step_(flat, grad, opt_m, opt_v, lr, b1, b2, eps, step, grad_scale=scale, sq_norms=sq_norms)
+    return scale
 
 
 def load_params(path: str, coarse: ModelBase, fine: ModelBase, device) -> Dict[str, Any]:

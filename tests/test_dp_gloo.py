@@ -98,18 +98,17 @@ def test_two_rank_gradient_equals_global_batch(tmp_path):
 
 
 class CpuKernels:
-    """CPU stand-in for the two HIP kernel families TrainLoop's update uses (ops.sq_norm_into, ops.adam_step_),
-    with the oracle's Adam (oracle/train.py) — so that train.apply_gradients, the PRODUCT's reduce -> 1/W ->
-    norms -> Adam sequence, can run on CPU tensors under gloo."""
+    """CPU stand-in for the HIP kernel TrainLoop's update uses (ops.adam_step_ with fused norm accumulation), with
+    the oracle's Adam (oracle/train.py) — so that train.apply_gradients, the PRODUCT's reduce -> 1/W -> Adam (+ norms)
+    sequence, can run on CPU tensors under gloo."""
 
     @staticmethod
-    def sq_norm_into(x, out):
-        out.copy_((x.double() ** 2).sum().reshape(1).to(out.dtype))
-
-    @staticmethod
-    def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+    def adam_step_(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, sq_norms=None):
         from oracle import train as OT
 
+        if sq_norms is not None:  # what lnrf_adam_step_norms accumulates: the gradient as passed in, p before the update
+            sq_norms[0] += float((g.double() ** 2).sum())
+            sq_norms[1] += float((p.double() ** 2).sum())
         p2, m2, v2 = OT.adam_update(p.double(), g.double() * grad_scale, m.double(), v.double(), step, lr, b1, b2, eps)
         p.copy_(p2.to(p.dtype))
         m.copy_(m2.to(m.dtype))
@@ -132,8 +131,10 @@ def _update_worker(rank, world, port, out_dir):
     logs = []
     for step in (1, 2):  # two steps: the second one sees non-zero moments
         g = grad.clone() * (1.0 if step == 1 else 0.5)
-        log = apply_gradients(flat, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7, kernels=CpuKernels)
-        logs.append({k: float(x) for k, x in log.items()})
+        sq = torch.zeros(2, dtype=torch.float64)
+        scale = apply_gradients(flat, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7, sq_norms=sq, kernels=CpuKernels)
+        assert scale == 1.0 / world
+        logs.append(dict(grad_norm=float(sq[0].sqrt()) * scale, param_norm=float(sq[1].sqrt())))
     torch.save(dict(flat=flat, m=m, v=v, logs=logs), os.path.join(out_dir, f"u{rank}.pt"))
     import torch.distributed as dist
 

@@ -101,6 +101,19 @@ def test_adam_and_sq_norm(n):
     ops.sq_norm_into(pd, out)
     ref = (pd.cpu().double() ** 2).sum().item()
     assert abs(out.item() - ref) <= 1e-5 * ref
+    # fused variant: same update, plus sum g^2 (as passed in) and sum p^2 (before the update) in the same pass
+    p2, m2, v2 = pd.clone(), md.clone(), vd.clone()
+    sums = torch.zeros(4, device="cuda")
+    sums[0], sums[1] = 6.0, 12.0  # stand-ins for the step's squared-error sums
+    gg = (g * 4).cuda()
+    ops.adam_step_(p2, gg, m2, v2, 1e-4, 0.9, 0.999, 1e-7, 4, grad_scale=0.5, sq_norms=sums[2:4])
+    ops.adam_step_(pd, gg, md, vd, 1e-4, 0.9, 0.999, 1e-7, 4, grad_scale=0.5)
+    assert torch.equal(p2, pd) and torch.equal(m2, md) and torch.equal(v2, vd)
+    log = ops.step_log(sums, 0.5, 0.5, clear=True).cpu().double()
+    g_ref = (gg.cpu().double() ** 2).sum().sqrt().item() * 0.5
+    assert abs(log[0] - 3.0) < 1e-6 and abs(log[1] - 6.0) < 1e-6
+    assert abs(log[2] - g_ref) <= 1e-5 * g_ref and abs(log[3] - ref ** 0.5) <= 1e-5 * ref ** 0.5
+    assert (sums == 0).all()  # cleared for the next step
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
