@@ -8,6 +8,7 @@
 // 16 tables thrashing it.  The encoding is written feature-major ([L*F][M]) so that both the gather
 // kernel's stores and the scatter kernel's gradient loads are fully coalesced; the tiny MLP reads it
 // through the strided GEMM.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -75,14 +76,32 @@ __device__ __forceinline__ unsigned entry_index(unsigned cx, unsigned cy, unsign
   return cx + (unsigned)G * (cy + (unsigned)G * cz);                            // :199-201
 }
 
+struct LevelList {
+  int n;
+  int level[kMaxLevels];
+};
+
 // enc_t[(2*level + f) * M + m]
 // u == nullptr: the encoding.  u != nullptr ([M,3]): its directional derivative (d enc / d x) u.
-__global__ void hashgrid_fwd_kernel(HashGridDesc d, const float* __restrict__ tables,
+// STAGE: the level's whole table (dense levels of at most kStageEntries entries, i.e. the 16^3 grids that every
+// sample of the batch hits) is first copied into LDS with coalesced 16-byte loads and the 8 corner reads of every
+// sample are LDS reads; the launch uses few, long-lived workgroups so that one copy serves thousands of samples.
+constexpr int kStageEntries = 8192;  // 64 KiB of float2
+template <bool STAGE>
+__global__ void hashgrid_fwd_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ tables,
                                     const float* __restrict__ x, const float* __restrict__ u, int64_t M,
                                     float* __restrict__ enc_t) {
-  const int level = blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+  const int level = ll.level[blockIdx.y];
   const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
   const float2* __restrict__ tab = reinterpret_cast<const float2*>(tables + d.table_offset[level]);
+  if (STAGE) {
+    // table_offset is a multiple of 2 floats (F = 2), i.e. 8-byte aligned: copy as float2, fully coalesced
+    float2* lt = reinterpret_cast<float2*>(lds_tab);
+    for (int i = threadIdx.x; i < T; i += blockDim.x) lt[i] = tab[i];
+    __syncthreads();
+    tab = lt;  // generic pointer into LDS: the gathers below become ds_read_b64
+  }
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
     const Corner k = locate(p, d, G);
@@ -114,10 +133,6 @@ __global__ void hashgrid_fwd_kernel(HashGridDesc d, const float* __restrict__ ta
 // g_tables[level][idx][f] += w * g_enc_t[(2*level+f)*M + m].  Levels whose whole table fits in LDS
 // (G^3 * 8 B <= 64 KiB, i.e. the 16^3 levels that thousands of samples share) are pre-reduced in LDS and
 // flushed once per workgroup; the other levels use fp32 atomics directly.
-struct LevelList {
-  int n;
-  int level[kMaxLevels];
-};
 
 __global__ void hashgrid_bwd_kernel(HashGridDesc d, LevelList ll, const float* __restrict__ x,
                                     const float* __restrict__ u, int64_t M,
@@ -479,6 +494,15 @@ static int check_desc(const lnrf_hashgrid_desc* d) {
 
 static_assert(sizeof(HashGridDesc) == sizeof(lnrf_hashgrid_desc), "descriptor layout");
 
+// LNRF_HASHGRID_LDS=0 in the environment turns the LDS-staged gather off (A/B measurements); default on
+static bool lds_staging_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("LNRF_HASHGRID_LDS");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
 extern "C" int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, int64_t m,
                                  float* enc_t, lnrf_stream_t stream) {
   return lnrf_hashgrid_jvp(desc, tables, x, nullptr, m, enc_t, stream);
@@ -493,11 +517,36 @@ extern "C" int lnrf_hashgrid_jvp(const lnrf_hashgrid_desc* desc, const float* ta
   if (m == 0) return LNRF_OK;
   HashGridDesc d;
   memcpy((void*)&d, (const void*)desc, sizeof(d));
-  int64_t bx = (m + 255) / 256;
-  if (bx > 4096) bx = 4096;
-  hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)bx, (unsigned)d.n_levels), dim3(256), 0, as_stream(stream),
-                     d, tables, x, u, m, enc_t);
-  LNRF_LAUNCH_CHECK();
+  // dense levels whose table fits in 64 KiB of LDS are staged there (LDS gather); the others gather from L2 / HBM
+  LevelList staged, direct;
+  staged.n = direct.n = 0;
+  for (int l = 0; l < d.n_levels; ++l) {
+    if (lds_staging_enabled() && !d.hashed[l] && d.table_size[l] <= kStageEntries && m >= 16384)
+      staged.level[staged.n++] = l;
+    else direct.level[direct.n++] = l;
+  }
+  if (direct.n > 0) {
+    int64_t bx = (m + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<false>, dim3((unsigned)bx, (unsigned)direct.n), dim3(256), 0,
+                       as_stream(stream), d, direct, tables, x, u, m, enc_t);
+    LNRF_LAUNCH_CHECK();
+  }
+  if (staged.n > 0) {
+    // one table copy (32 KiB for a 16^3 grid, read from L2) per 512-thread workgroup and >= 1024 samples; LDS is
+    // sized to the largest staged table so that four such workgroups share a CU
+    int max_rows = 0;
+    for (int i = 0; i < staged.n; ++i)
+      if (d.table_size[staged.level[i]] > max_rows) max_rows = d.table_size[staged.level[i]];
+    int64_t bx = (m + 1023) / 1024;
+    if (bx > 1024) bx = 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_fwd_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kStageEntries * 8);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+    hipLaunchKernelGGL(hashgrid_fwd_kernel<true>, dim3((unsigned)bx, (unsigned)staged.n), dim3(512), max_rows * 8,
+                       as_stream(stream), d, staged, tables, x, u, m, enc_t);
+    LNRF_LAUNCH_CHECK();
+  }
   return LNRF_OK;
 }
 

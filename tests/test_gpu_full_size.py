@@ -106,6 +106,36 @@ def test_full_size_hashgrid_properties():
         for f in range(2):
             assert enc_t[2 * l + f].min() >= tab[:, f].min() - 1e-6 and enc_t[2 * l + f].max() <= tab[:, f].max() + 1e-6
         off += 2 * rows
+    # (1b) ORACLE at the real table size: 4,096 of the evaluations, all 16 levels (6 dense incl. the LDS-staged 16^3
+    # ones, 10 hashed with T = 2^19), against oracle/instant_ngp.py on the same tables — a wrong hash index, prime,
+    # wrap-around or dense/hashed switch shows here (the properties above and below cannot see one)
+    from oracle import instant_ngp as ONGP
+
+    sel = torch.randperm(m, generator=gen)[:4096]
+    xs = x[sel.cuda()].cpu().double()
+    bmin64, bmax64 = torch.tensor(BMIN, dtype=F64), torch.tensor(BMAX, dtype=F64)
+    off = 0
+    for l, (rows, gsz) in enumerate(zip(enc.rows(), enc.grid_sizes)):
+        tab = tables[off:off + 2 * rows].view(rows, 2).cpu().double()
+        ref = ONGP.hash_table_encoding(xs, tab, gsz, 2 ** 19, bmin64, bmax64)
+        got = enc_t[2 * l:2 * l + 2][:, sel.cuda()].t().cpu().double()
+        err = (got - ref).abs().max().item()
+        # fp32 cell coordinate fi = (G - 1) * frac carries ~G * 2^-23 of rounding into the interpolation weight of
+        # U(-1, 1) entries; an index error (hash, prime, wrap-around, dense/hashed switch) would be O(1)
+        assert err < 1e-5 + 6e-7 * gsz, (l, gsz, err)
+        off += 2 * rows
+    # scatter-add of the same subset against the oracle's autograd (table gradient of sum(g * enc))
+    gsub = torch.randn(2 * levels, 4096, generator=gen).float()
+    gts = torch.zeros(nt, device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x[sel.cuda()].contiguous(), gsub.cuda().contiguous(), gts)
+    off = 0
+    for l, (rows, gsz) in enumerate(zip(enc.rows(), enc.grid_sizes)):
+        tab = tables[off:off + 2 * rows].view(rows, 2).cpu().double().requires_grad_(True)
+        out = ONGP.hash_table_encoding(xs, tab, gsz, 2 ** 19, bmin64, bmax64)
+        (gref,) = torch.autograd.grad((out * gsub[2 * l:2 * l + 2].t().double()).sum(), tab)
+        got = gts[off:off + 2 * rows].view(rows, 2).cpu().double()
+        assert ((got - gref).abs().max() / gref.abs().max()).item() < 1e-5 + 6e-7 * gsz, (l, gsz)  # same fp32 weights
+        off += 2 * rows
     # (2) scatter-add: the trilinear weights of a sample sum to 1, so per level and feature the gradient table
     # sums to the sum of the incoming gradients; it is linear in them; entries are reproducible
     g = torch.randn(2 * levels, m, generator=gen).float().cuda()
