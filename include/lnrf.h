@@ -355,6 +355,34 @@ int lnrf_nerf_mlp_bwd_chain(const lnrf_nerf_shape* shape, const void* packed, co
 int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
                               int64_t m, float* grads, lnrf_stream_t stream);
 
+/* ---- fused spatial block of RefNERFModel (reference learn_nerf/ref_nerf.py:80-107; csrc/refnerf_fused.hip) ----
+ * The spatial block of RefNERFModel is the NeRFModel trunk (Dense_0..8: 60 -> 256 x5, 316 -> 256, 256 x3, default
+ * widths and x_freqs = 10 only; parameters in Flax creation order, so Dense_0..8 sit where they sit in NeRFModel's
+ * vector).  These entries run it — and everything that differentiates through it — on the fused bf16-MFMA chain:
+ *   lnrf_refnerf_trunk_pack     fp32 parameters -> opaque fragment streams (lnrf_refnerf_trunk_packed_bytes bytes)
+ *   lnrf_refnerf_trunk_fwd      spatial_out[m, 0:256] (fp32, `ld` floats per row, rows 16-byte aligned) =
+ *                               spatial_block(x) (ref_nerf.py:37); `save` (lnrf_nerf_save_bytes of the default
+ *                               lnrf_nerf_shape) receives the bf16 activations and ReLU masks of the pass
+ *   lnrf_refnerf_normal_pass    n_raw[m, 3] = -d spatial_out[:, 0] / dx (ref_nerf.py:38-43: the jax.grad inside
+ *                               RefNERFBase.__call__); cdump (lnrf_nerf_bwd_scratch_bytes) keeps the chain states
+ *   lnrf_refnerf_trunk_bwd      grads += d L / d Dense_0..8 given g_spatial = d L / d spatial_out [m, ld]
+ *                               (first-order path; scratch: lnrf_nerf_bwd_scratch_bytes)
+ *   lnrf_refnerf_normal_bwd     grads += the second-order term: d L / d Dense_0..8 through n_raw, given
+ *                               u = d L / d n_raw [m, 3] (jax.grad of a function that calls jax.grad, train.py:89-90
+ *                               over ref_nerf.py:42; scratch: lnrf_nerf_save_bytes)
+ * Head, integrated directional encoding and the 273 -> 128 -> 3 directional block: lnrf_refnerf_head_*,
+ * lnrf_refnerf_color_*, lnrf_dense_*. */
+int64_t lnrf_refnerf_trunk_packed_bytes(void);
+int lnrf_refnerf_trunk_pack(const float* params, void* packed, lnrf_stream_t stream);
+int lnrf_refnerf_trunk_fwd(const void* packed, const float* x, int64_t m, void* save, float* spatial_out,
+                           int64_t ld, lnrf_stream_t stream);
+int lnrf_refnerf_normal_pass(const void* packed, const void* save, const float* x, int64_t m, void* cdump,
+                             float* nraw, lnrf_stream_t stream);
+int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, const float* g_spatial, int64_t ld, int64_t m,
+                           void* scratch, float* grads, lnrf_stream_t stream);
+int lnrf_refnerf_normal_bwd(const void* packed, const void* save, const void* cdump, const float* x,
+                            const float* u, int64_t m, void* scratch, float* grads, lnrf_stream_t stream);
+
 /* ------------------------------------------------------- data-parallel exchange ---- */
 
 /* One process per GPU; rays shard across ranks and the ONLY exchange of a training step is one all-reduce (sum) of

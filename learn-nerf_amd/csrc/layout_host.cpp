@@ -49,6 +49,14 @@ int lnrf_host_fwd_bias_index(int i) {
     if (i >= fwd_bias_base(k)) s = k;
   return fwd_bias_index(s, i - fwd_bias_base(s));
 }
+int lnrf_host_nrm_frags(void) { return kNrmFrags; }
+int lnrf_host_nrm_weight_index(int g, int lane, int j) {
+  int u = 0;
+  for (int i = 1; i < kNrmLayers; ++i)
+    if (g >= nrm_base(i)) u = i;
+  const int loc = g - nrm_base(u);
+  return nrm_weight_index(u, loc / nrm_nk(u), loc % nrm_nk(u), lane, j);
+}
 int lnrf_host_xemb_feat(int ks, int h, int j) { return xemb_feat(ks, h, j); }
 int lnrf_host_demb_feat(int ks, int h, int j) { return demb_feat(ks, h, j); }
 int lnrf_host_dump_lane_off(int slot, int c, int hh) { return dump_lane_off(slot, c, hh); }

@@ -215,11 +215,54 @@ NL_HD constexpr int bwd_weight_index(int t, int o, int ks, int lane, int j) {
   return dense_w_off(l) + in * 256 + hidden_feat(ks, h, j);
 }
 
+// ---- Ref-NeRF normal-pass weight stream (ref_nerf.py:38-43: n = -d out[:, 0] / dx) ----------------------------
+// The analytic normal is an input-gradient chain through the spatial block Dense_8 .. Dense_0 (same trunk as
+// NeRFModel) down to the positional embedding.  Stream layers u, in consumption order:
+//   0,1,2 = Dense_8,7,6^T | 3 = "X5": the x_emb rows of Dense_5 (316-wide input, rows 256..315) applied to dy5 |
+//   4 = Dense_5^T (h rows) | 5..8 = Dense_4..1^T | 9 = "X0": Dense_0^T applied to dy0.
+// X layers: k = hidden feature of the layer's output gradient, 16 k-steps x 2 out tiles; the 64 A rows are ordered
+// so that every lane of the result tile holds BOTH the sin and the cos row of its (coordinate, frequency) pairs:
+// result register q of lane half hh in tile o <-> pair pg = 16 o + 8 hh + (q >> 1) = 10 a + f (30 real pairs),
+// row e = 20 a + f + 10 (q & 1) of model.py:72-77 (nrm_x_row); one sincos per pair applies the embedding Jacobian.
+constexpr int kNrmLayers = 10;
+NL_HD constexpr bool nrm_is_x(int u) { return u == 3 || u == 9; }
+NL_HD constexpr int nrm_nk(int) { return 16; }
+NL_HD constexpr int nrm_no(int u) { return nrm_is_x(u) ? 2 : 8; }
+NL_HD constexpr int nrm_base(int u) {
+  int b = 0;
+  for (int i = 0; i < u; ++i) b += nrm_nk(i) * nrm_no(i);
+  return b;
+}
+constexpr int kNrmFrags = nrm_base(kNrmLayers);  // 1088, every layer a whole number of 16-fragment stages
+static_assert(kNrmFrags == 1088 && kNrmFrags % kStageFrags == 0, "normal-pass stream length");
+NL_HD constexpr int nrm_seq(int c) { return c; }
+// Dense layer applied by hidden stream layer u (u not an X layer)
+NL_HD constexpr int nrm_dense(int u) { return u < 3 ? 8 - u : (u == 4 ? 5 : 9 - u); }  // 0->8 1->7 2->6 4->5 5->4 .. 8->1
+NL_HD constexpr int nrm_x_row(int o, int r) {  // result row r = (q & 3) + 8 (q >> 2) + 4 hh  ->  embedding feature
+  const int hh = (r >> 2) & 1, q = (r & 3) + 4 * (r >> 3);
+  const int pg = 16 * o + 8 * hh + (q >> 1);
+  if (pg >= 30) return -1;
+  return 20 * (pg / 10) + (pg % 10) + 10 * (q & 1);
+}
+NL_HD constexpr int nrm_weight_index(int u, int o, int ks, int lane, int j) {
+  const int r = lane & 31, h = lane >> 5;
+  const int k = hidden_feat(ks, h, j);
+  if (nrm_is_x(u)) {
+    const int e = nrm_x_row(o, r);  // embedding feature fed by result row r of tile o
+    if (e < 0) return -1;
+    return u == 3 ? dense_w_off(5) + (256 + e) * 256 + k : dense_w_off(0) + e * 256 + k;
+  }
+  return dense_w_off(nrm_dense(u)) + (32 * o + r) * 256 + k;  // row of the Flax kernel = input feature
+}
+
 // ---- packed parameter blob --------------------------------------------------------------------
 constexpr int64_t kPackFwdOff = 0;
 constexpr int64_t kPackBwdOff = (int64_t)kFwdFrags * kFragBytes;
 constexpr int64_t kPackBiasOff = kPackBwdOff + (int64_t)kBwdFrags * kFragBytes;
 constexpr int64_t kPackBytes = kPackBiasOff + round_up(kBiasFloats * 4, 1024);
+// Ref-NeRF trunk blob: the NeRFModel blob (head layers zero) followed by the normal-pass stream
+constexpr int64_t kRefPackNrmOff = kPackBytes;
+constexpr int64_t kRefPackBytes = kRefPackNrmOff + (int64_t)kNrmFrags * kFragBytes;
 
 // ---- saved activations / gradient dumps -------------------------------------------------------
 // Both buffers are [slot][tile][1 KiB]; a slot is one k-step (16 features) of one tensor.

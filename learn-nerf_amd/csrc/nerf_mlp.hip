@@ -701,6 +701,18 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
   return lnrf_nerf_mlp_bwd_weights(shape, save, scratch, m, grads, stream);
 }
 
+int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
+                            float* grads, hipStream_t stream) {
+  const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_wgrad_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+  hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args, (const char*)xbuf,
+                     (const char*)ybuf, n_tiles, grads);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
 extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
                                          int64_t m, float* grads, lnrf_stream_t stream) {
   if (!shape_supported(shape)) {
@@ -717,13 +729,8 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   WgradArgs a;
   const int blocks[13] = {48, 48, 48, 48, 47, 47, 47, 47, 39, 30, 30, 18, 15};
   const int first = build_wgrad_problems(a, blocks, (n_tiles + 5) / 6);
-  const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
-  rc = ensure_lds(nerf_wgrad_kernel, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)first), dim3(kThreads), lds, st, a, (const char*)save,
-                     (const char*)scratch, n_tiles, grads);
-  LNRF_LAUNCH_CHECK();
-  return LNRF_OK;
+  (void)rc;
+  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st);
 }
 
 #ifdef LNRF_TIMELINE

@@ -1,0 +1,563 @@
+// refnerf_fused.hip — the spatial block of RefNERFModel (ref_nerf.py:92-99: Dense_0..8, the NeRFModel trunk) and
+// everything that differentiates through it, on the fused bf16-MFMA chain of nerf_mlp.hip / nerf_chain.h:
+//
+//   trunk forward   spatial_out = Dense_8(...)  (fp32, row-major for the head kernels) + saved bf16 activations / masks
+//   normal pass     n_raw = -d spatial_out[:, 0] / dx (ref_nerf.py:38-43): the input-gradient chain with the seed
+//                   -e_0, continued through the x_emb rows of Dense_5 and through Dense_0 into the positional
+//                   embedding, whose Jacobian is applied in registers; dumps the chain states c_l
+//   trunk backward  first-order: d L / d spatial_out -> dy_l chain -> dW_l = X_l^T dy_l (nerf_wgrad_kernel)
+//   normal backward second-order: the normal enters the loss (normal_mse, ref_nerf.py:73), and with the ReLU masks
+//                   fixed the normal pass is multilinear in the kernels: tbar_l = mask_l * (tbar_{l-1} W_l) seeded by
+//                   (d emb / dx) u, u = d L / d n_raw; dW_l += tbar_{l-1}^T c_l (the same weight-gradient kernel on
+//                   the tangent dump and the c dump)
+//
+// The head (exp / sigmoid / softplus heads, reflection, integrated directional encoding, aux losses: refnerf.hip) and
+// the 273 -> 128 -> 3 directional block (dense.hip) stay separate kernels; they are 6 % of the model's FLOPs.
+// Precision: bf16 operands, fp32 accumulate, fp32 bias / embedding / head inputs — the arithmetic of the dense bf16
+// path that these kernels replace (precision="fp32" keeps the exact dense path).
+#include "nerf_chain.h"
+
+namespace lnrf {
+
+constexpr int kRefLds = kRingBytes + round_up(kBiasFloats * 4, 1024);
+
+template <int COUNT>
+struct LinSeq {  // a stream consumed front to back without padding
+  static constexpr int count = COUNT;
+  static constexpr int at(int c) { return c; }
+};
+template <int LAYERS>
+struct FwdPrefixSeq {  // the forward stream up to (not including) stream layer LAYERS
+  static constexpr int count = fwd_cons_base(LAYERS);
+  static constexpr int at(int c) { return fwd_seq(c); }
+};
+
+__device__ __forceinline__ void load_relu_masks(uint4 (&mask)[8], const char* __restrict__ save, int64_t n_tiles,
+                                                int64_t tile, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    mask[i] = *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) * kFragBytes + lane * 16);
+}
+// ReLU mask of h_i (written by the trunk forward), 16 bytes per lane
+__device__ __forceinline__ uint4 load_relu_mask(int i, const char* __restrict__ save, int64_t n_tiles, int64_t tile,
+                                                int lane) {
+  return *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) * kFragBytes + lane * 16);
+}
+__device__ __forceinline__ unsigned mask_word(const uint4& mk, int o) {
+  return (o >> 1) == 0 ? mk.x : ((o >> 1) == 1 ? mk.y : ((o >> 1) == 2 ? mk.z : mk.w));
+}
+
+// ---------------------------------------------------------------------------------------------
+// trunk forward: Dense_0..8 (model.py:50-56 as used by ref_nerf.py:92-99), saving what the backward passes need
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void refnerf_trunk_fwd_kernel(
+    const char* __restrict__ packed, const float* __restrict__ xin_g, int64_t M, int64_t n_tiles,
+    char* __restrict__ save, float* __restrict__ zout, int64_t ldz) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  {
+    const float* bias_g = reinterpret_cast<const float*>(packed + kPackBiasOff);
+    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
+    for (int i = tid; i < kBiasFloats; i += kThreads) bias_l[i] = bias_g[i];
+  }
+  float px[3] = {0, 0, 0};
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) px[a] = xin_g[m * 3 + a];
+  }
+  __syncthreads();
+  Ring<fwd_base(9) / kStageFrags, FwdPrefixSeq<9>> ring;
+  ring.stream = packed + kPackFwdOff;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+
+  bf16x8 xe[4];
+  static_for<4>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int p = 4 * ks + pp;
+      float s = 0.0f, co = 0.0f;
+      if (p < 15) {
+        const int pg = 15 * h + p;
+        const int cd = pg / 10, f = pg - 10 * cd;
+        const float v = cd == 0 ? px[0] : (cd == 1 ? px[1] : px[2]);
+        sincos_pe(v * (float)(1 << f), &s, &co);
+      }
+      xe[ks][2 * pp] = (__bf16)s;
+      xe[ks][2 * pp + 1] = (__bf16)co;
+    }
+  });
+  DumpAddr dump{save, n_tiles, tile, c, h};
+  static_for<4>([&](auto i) { stream_store(dump.at(kSaveXin + decltype(i)::value), frag_to_bits(xe[decltype(i)::value])); });
+
+  bf16x8 a0[16], a1[16];
+  unsigned mask_bits[4] = {0u, 0u, 0u, 0u};
+  auto hidden = [&](auto s_, bf16x8(&in)[16], bf16x8(&out)[16]) {
+    constexpr int S = decltype(s_)::value;
+    chain_layer<fwd_cons_base(S), fwd_nk(S), fwd_no(S)>(
+        ring, [&](auto o_) { return bias_acc(fwd_bias_base(S) + 32 * decltype(o_)::value, h); },
+        [&](auto k_) -> bf16x8 {
+          constexpr int ks = decltype(k_)::value;
+          if constexpr (S == 0) return xe[ks];
+          else if constexpr (ks < 16) return in[ks];
+          else return xe[ks - 16];
+        },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          out[2 * o] = acc_to_frag<0, true>(acc);
+          out[2 * o + 1] = acc_to_frag<1, true>(acc);
+          stream_store(dump.at(kSaveH + 16 * S + 2 * o), frag_to_bits(out[2 * o]));
+          stream_store(dump.at(kSaveH + 16 * S + 2 * o + 1), frag_to_bits(out[2 * o + 1]));
+          mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
+        });
+    *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile) * kFragBytes + lane * 16) =
+        make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
+    mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
+  };
+  hidden(std::integral_constant<int, 0>{}, a1, a0);
+  hidden(std::integral_constant<int, 1>{}, a0, a1);
+  hidden(std::integral_constant<int, 2>{}, a1, a0);
+  hidden(std::integral_constant<int, 3>{}, a0, a1);
+  hidden(std::integral_constant<int, 4>{}, a1, a0);
+  hidden(std::integral_constant<int, 5>{}, a0, a1);
+  hidden(std::integral_constant<int, 6>{}, a1, a0);
+  hidden(std::integral_constant<int, 7>{}, a0, a1);
+  // Dense_8: linear spatial_out (ref_nerf.py:98-99), fp32, row m of a row-major matrix with ldz floats per row
+  chain_layer<fwd_cons_base(8), fwd_nk(8), fwd_no(8)>(
+      ring, [&](auto o_) { return bias_acc(fwd_bias_base(8) + 32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 { return a1[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        if (valid) {
+          float* zr = zout + m * ldz + 32 * o + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(zr + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+      });
+}
+
+// One hidden step of an input-gradient chain: out = relu'(h_{l-1}) * (W_l^T in), dumped as dy_{l-1} / c_{l-1}
+template <int C0, int L, class RING>
+__device__ __forceinline__ void hidden_back(RING& ring, bf16x8 (&in)[16], bf16x8 (&out)[16], const uint4& mk,
+                                            const DumpAddr& gd) {
+  chain_layer<C0, 16, 8>(
+      ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return in[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        const unsigned mb = mask_word(mk, o);
+        out[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
+        out[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
+        stream_store(gd.at(grad_dy_slot(L - 1) + 2 * o), frag_to_bits(out[2 * o]));
+        stream_store(gd.at(grad_dy_slot(L - 1) + 2 * o + 1), frag_to_bits(out[2 * o + 1]));
+      });
+}
+
+// ---------------------------------------------------------------------------------------------
+// normal pass (ref_nerf.py:38-43)
+// ---------------------------------------------------------------------------------------------
+// J^T applied to one 32-row tile of the embedding gradient (rows ordered by nrm_x_row: registers 2i, 2i + 1 of a lane
+// are the sin and the cos row of pair pg = 16 o + 8 hh + i = 10 a + f):  d sin(2^f x)/dx = 2^f cos, d cos = -2^f sin.
+// The 8 pairs of a lane are consecutive frequencies of at most two coordinates: two exact sincos (first pair, and
+// frequency 0 of the next coordinate) and angle doubling in between — a dependency chain with two live values instead
+// of eight interleaved range reductions (which cost ~100 registers and spilled).  Doubling error <= 2^7 x 1e-7.
+template <int O>
+__device__ __forceinline__ void emb_bwd_tile(const f32x16& acc, const float (&px)[3], int hh, float (&nr)[3]) {
+  const int base = 16 * O + 8 * hh;
+  const int a0 = base / 10, f0 = base - 10 * a0;
+  const int ri = 10 - f0;  // pair index at which the next coordinate starts (>= 8: not in this lane)
+  const float xa0 = a0 == 0 ? px[0] : (a0 == 1 ? px[1] : px[2]);
+  const float xa1 = a0 == 0 ? px[1] : px[2];
+  float sc = (float)(1 << f0);
+  float s, co, s1, c1;
+  sincos_pe(xa0 * sc, &s, &co);
+  sincos_pe(xa1, &s1, &c1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i > 0) {
+      const bool restart = i == ri;
+      const float sd = 2.0f * s * co, cd = co * co - s * s;
+      s = restart ? s1 : sd;
+      co = restart ? c1 : cd;
+      sc = restart ? 1.0f : 2.0f * sc;
+    }
+    const int a = i >= ri ? a0 + 1 : a0;
+    const float t = base + i < 30 ? sc * (co * acc[2 * i] - s * acc[2 * i + 1]) : 0.0f;
+    nr[0] += a == 0 ? t : 0.0f;
+    nr[1] += a == 1 ? t : 0.0f;
+    nr[2] += a == 2 ? t : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void refnerf_normal_kernel(
+    const char* __restrict__ packed, const char* __restrict__ save, const float* __restrict__ xin_g, int64_t M,
+    int64_t n_tiles, char* __restrict__ cdump, float* __restrict__ nraw) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  float px[3] = {0, 0, 0};
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) px[a] = xin_g[m * 3 + a];
+  }
+  // masks are fetched one layer ahead instead of all eight up front: the X layers need the registers
+  auto mask_of = [&](int i) { return load_relu_mask(i, save, n_tiles, tile, lane); };
+  uint4 mk = mask_of(7), mk_next = mask_of(6);
+  __syncthreads();
+  Ring<kNrmFrags / kStageFrags, LinSeq<kNrmFrags>> ring;
+  ring.stream = packed + kRefPackNrmOff;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+
+  DumpAddr gd{cdump, n_tiles, tile, c, h};
+  bf16x8 a0[16], a1[16];
+  // seed c_8 = -e_0: feature 0 is k slot (ks 0, h 0, j 0)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a1[i] = zero_frag();
+  if (h == 0) a1[0][0] = (__bf16)(-1.0f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stream_store(gd.at(grad_dy_slot(8) + i), frag_to_bits(a1[i]));
+
+  float nr[3] = {0.0f, 0.0f, 0.0f};
+  auto x_layer = [&](auto u_, bf16x8(&in)[16]) {
+    constexpr int U = decltype(u_)::value;
+    chain_layer<nrm_base(U), 16, 2>(
+        ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return in[decltype(k_)::value]; },
+        [&](auto o_, const f32x16& acc) {
+          // The sin / cos values depend on x only, so the compiler would compute them once and keep the 60 of them
+          // alive from the first X layer to the second (spills); an empty asm makes each use recompute its own.
+          float pl[3] = {px[0], px[1], px[2]};
+          asm volatile("" : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]));
+          emb_bwd_tile<decltype(o_)::value>(acc, pl, h, nr);
+        });
+  };
+  auto advance_mask = [&](int next) {
+    mk = mk_next;
+    if (next >= 0) mk_next = mask_of(next);
+  };
+  hidden_back<nrm_base(0), 8>(ring, a1, a0, mk, gd);  // c_7
+  advance_mask(5);
+  hidden_back<nrm_base(1), 7>(ring, a0, a1, mk, gd);  // c_6
+  advance_mask(4);
+  hidden_back<nrm_base(2), 6>(ring, a1, a0, mk, gd);  // c_5
+  advance_mask(3);
+  x_layer(std::integral_constant<int, 3>{}, a0);      // x_emb rows of Dense_5 (model.py:52 concat) on c_5
+  hidden_back<nrm_base(4), 5>(ring, a0, a1, mk, gd);  // c_4
+  advance_mask(2);
+  hidden_back<nrm_base(5), 4>(ring, a1, a0, mk, gd);  // c_3
+  advance_mask(1);
+  hidden_back<nrm_base(6), 3>(ring, a0, a1, mk, gd);  // c_2
+  advance_mask(0);
+  hidden_back<nrm_base(7), 2>(ring, a1, a0, mk, gd);  // c_1
+  advance_mask(-1);
+  hidden_back<nrm_base(8), 1>(ring, a0, a1, mk, gd);  // c_0
+  x_layer(std::integral_constant<int, 9>{}, a1);      // Dense_0^T on c_0
+#pragma unroll
+  for (int a = 0; a < 3; ++a) nr[a] += __shfl_xor(nr[a], 32, 64);  // the two lane halves hold different rows
+  if (h == 0 && valid) {
+    nraw[m * 3 + 0] = nr[0];
+    nraw[m * 3 + 1] = nr[1];
+    nraw[m * 3 + 2] = nr[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trunk backward, chain part: d L / d spatial_out [M, ldg] (fp32) -> dy_8 .. dy_0 dumps
+// ---------------------------------------------------------------------------------------------
+constexpr int kHiddenBwdOff = bwd_base(2);                 // fragments of T0 / T1 (unused by this model)
+constexpr int kHiddenBwdFrags = kBwdFrags - kHiddenBwdOff;  // 8 x 128
+static_assert(kHiddenBwdOff % kStageFrags == 0 && kHiddenBwdFrags == 1024, "hidden part of the transposed stream");
+
+__global__ __launch_bounds__(kThreads) void refnerf_trunk_bwd_chain_kernel(
+    const char* __restrict__ packed, const char* __restrict__ save, const float* __restrict__ g_z, int64_t ldg,
+    int64_t M, int64_t n_tiles, char* __restrict__ gdump) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  uint4 mask[8];
+  load_relu_masks(mask, save, n_tiles, tile, lane);
+  bf16x8 a0[16], a1[16];
+  // seed dy_8 = bf16(d L / d spatial_out): k slot (ks, h, j) <-> feature 16 ks + 8 (j >> 2) + 4 h + (j & 3)
+  static_for<16>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    float4 lo = make_float4(0, 0, 0, 0), hi = make_float4(0, 0, 0, 0);
+    if (valid) {
+      const float* gr = g_z + m * ldg + 16 * ks + 4 * h;
+      lo = *reinterpret_cast<const float4*>(gr);
+      hi = *reinterpret_cast<const float4*>(gr + 8);
+    }
+    a1[ks][0] = (__bf16)lo.x; a1[ks][1] = (__bf16)lo.y; a1[ks][2] = (__bf16)lo.z; a1[ks][3] = (__bf16)lo.w;
+    a1[ks][4] = (__bf16)hi.x; a1[ks][5] = (__bf16)hi.y; a1[ks][6] = (__bf16)hi.z; a1[ks][7] = (__bf16)hi.w;
+  });
+  __syncthreads();
+  Ring<kHiddenBwdFrags / kStageFrags, LinSeq<kHiddenBwdFrags>> ring;
+  ring.stream = packed + kPackBwdOff + (int64_t)kHiddenBwdOff * kFragBytes;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+  DumpAddr gd{gdump, n_tiles, tile, c, h};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) stream_store(gd.at(grad_dy_slot(8) + i), frag_to_bits(a1[i]));
+  hidden_back<0 * 128, 8>(ring, a1, a0, mask[7], gd);
+  hidden_back<1 * 128, 7>(ring, a0, a1, mask[6], gd);
+  hidden_back<2 * 128, 6>(ring, a1, a0, mask[5], gd);
+  hidden_back<3 * 128, 5>(ring, a0, a1, mask[4], gd);
+  hidden_back<4 * 128, 4>(ring, a1, a0, mask[3], gd);
+  hidden_back<5 * 128, 3>(ring, a0, a1, mask[2], gd);
+  hidden_back<6 * 128, 2>(ring, a1, a0, mask[1], gd);
+  hidden_back<7 * 128, 1>(ring, a0, a1, mask[0], gd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// normal backward, tangent chain: ubar_e = (d emb / dx) u, tbar_l = relu'(h_l) * (tbar_{l-1} W_l), l = 0..7
+// (forward weight stream, no bias); dumps in the layout of the forward save buffer (x_emb and h slots)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void refnerf_tangent_kernel(
+    const char* __restrict__ packed, const char* __restrict__ save, const float* __restrict__ xin_g,
+    const float* __restrict__ u_g, int64_t M, int64_t n_tiles, char* __restrict__ tdump) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  float px[3] = {0, 0, 0}, pu[3] = {0, 0, 0};
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      px[a] = xin_g[m * 3 + a];
+      pu[a] = u_g[m * 3 + a];
+    }
+  }
+  uint4 mask[8];
+  load_relu_masks(mask, save, n_tiles, tile, lane);
+  __syncthreads();
+  Ring<fwd_base(8) / kStageFrags, FwdPrefixSeq<8>> ring;
+  ring.stream = packed + kPackFwdOff;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+
+  DumpAddr td{tdump, n_tiles, tile, c, h};
+  bf16x8 xe[4];
+  static_for<4>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int p = 4 * ks + pp;
+      float ts = 0.0f, tc = 0.0f;
+      if (p < 15) {
+        const int pg = 15 * h + p;
+        const int cd = pg / 10, f = pg - 10 * cd;
+        const float v = cd == 0 ? px[0] : (cd == 1 ? px[1] : px[2]);
+        const float uu = cd == 0 ? pu[0] : (cd == 1 ? pu[1] : pu[2]);
+        const float sc = (float)(1 << f);
+        float s, co;
+        sincos_pe(v * sc, &s, &co);
+        ts = sc * co * uu;   // d sin(2^f x) = 2^f cos(2^f x) dx
+        tc = -sc * s * uu;   // d cos(2^f x) = -2^f sin(2^f x) dx
+      }
+      xe[ks][2 * pp] = (__bf16)ts;
+      xe[ks][2 * pp + 1] = (__bf16)tc;
+    }
+    stream_store(td.at(kSaveXin + ks), frag_to_bits(xe[ks]));
+  });
+  bf16x8 a0[16], a1[16];
+  auto hidden = [&](auto s_, bf16x8(&in)[16], bf16x8(&out)[16]) {
+    constexpr int S = decltype(s_)::value;
+    chain_layer<fwd_cons_base(S), fwd_nk(S), fwd_no(S)>(
+        ring, [&](auto) { return zero_acc(); },
+        [&](auto k_) -> bf16x8 {
+          constexpr int ks = decltype(k_)::value;
+          if constexpr (S == 0) return xe[ks];
+          else if constexpr (ks < 16) return in[ks];
+          else return xe[ks - 16];
+        },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          const unsigned mb = mask_word(mask[S], o);
+          out[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
+          out[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
+          stream_store(td.at(kSaveH + 16 * S + 2 * o), frag_to_bits(out[2 * o]));
+          stream_store(td.at(kSaveH + 16 * S + 2 * o + 1), frag_to_bits(out[2 * o + 1]));
+        });
+  };
+  hidden(std::integral_constant<int, 0>{}, a1, a0);
+  hidden(std::integral_constant<int, 1>{}, a0, a1);
+  hidden(std::integral_constant<int, 2>{}, a1, a0);
+  hidden(std::integral_constant<int, 3>{}, a0, a1);
+  hidden(std::integral_constant<int, 4>{}, a1, a0);
+  hidden(std::integral_constant<int, 5>{}, a0, a1);
+  hidden(std::integral_constant<int, 6>{}, a1, a0);
+  hidden(std::integral_constant<int, 7>{}, a0, a1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing: the NeRFModel streams restricted to the trunk (head fragments zero) + the normal-pass stream
+// ---------------------------------------------------------------------------------------------
+__global__ void refnerf_pack_kernel(const float* __restrict__ params, char* __restrict__ packed) {
+  const int64_t total_f = (int64_t)kFwdFrags * 512;
+  const int64_t total_b = (int64_t)kBwdFrags * 512;
+  const int64_t total_n = (int64_t)kNrmFrags * 512;
+  const int64_t total = total_f + total_b + kBiasFloats + total_n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < total_f + total_b) {
+      const bool fwd = e < total_f;
+      const int64_t ee = fwd ? e : e - total_f;
+      const int g = (int)(ee >> 9), lane = (int)((ee >> 3) & 63), j = (int)(ee & 7);
+      int idx = -1;
+      if (fwd) {
+        int s = 0;
+        for (int i = 1; i < kFwdLayers; ++i)
+          if (g >= fwd_base(i)) s = i;
+        const int loc = g - fwd_base(s);
+        if (s <= 8 && loc < fwd_nk(s) * fwd_no(s)) idx = fwd_weight_index(s, loc / fwd_nk(s), loc % fwd_nk(s), lane, j);
+      } else {
+        int t = 0;
+        for (int i = 1; i < kBwdLayers; ++i)
+          if (g >= bwd_base(i)) t = i;
+        const int loc = g - bwd_base(t);
+        if (t >= 2 && loc < bwd_nk(t) * bwd_no(t)) idx = bwd_weight_index(t, loc / bwd_nk(t), loc % bwd_nk(t), lane, j);
+      }
+      const float v = idx >= 0 ? params[idx] : 0.0f;
+      reinterpret_cast<__bf16*>(packed + (fwd ? kPackFwdOff : kPackBwdOff))[ee] = (__bf16)v;
+    } else if (e < total_f + total_b + kBiasFloats) {
+      const int i = (int)(e - total_f - total_b);
+      int s = 0;
+      for (int k = 1; k < kFwdLayers; ++k)
+        if (i >= fwd_bias_base(k)) s = k;
+      const int idx = s <= 8 ? fwd_bias_index(s, i - fwd_bias_base(s)) : -1;
+      reinterpret_cast<float*>(packed + kPackBiasOff)[i] = idx >= 0 ? params[idx] : 0.0f;
+    } else {
+      const int64_t ee = e - total_f - total_b - kBiasFloats;
+      const int g = (int)(ee >> 9), lane = (int)((ee >> 3) & 63), j = (int)(ee & 7);
+      int u = 0;
+      for (int i = 1; i < kNrmLayers; ++i)
+        if (g >= nrm_base(i)) u = i;
+      const int loc = g - nrm_base(u);
+      const int idx = nrm_weight_index(u, loc / nrm_nk(u), loc % nrm_nk(u), lane, j);
+      reinterpret_cast<__bf16*>(packed + kRefPackNrmOff)[ee] = (__bf16)(idx >= 0 ? params[idx] : 0.0f);
+    }
+  }
+}
+
+}  // namespace lnrf
+
+using namespace lnrf;
+
+template <class K>
+static int set_lds(K kernel, int bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+  return LNRF_OK;
+}
+static inline dim3 tile_grid(int64_t n_tiles) { return dim3((unsigned)(n_tiles / kWaves)); }
+
+extern "C" int64_t lnrf_refnerf_trunk_packed_bytes(void) { return kRefPackBytes; }
+
+extern "C" int lnrf_refnerf_trunk_pack(const float* params, void* packed, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(params && packed, "null pointer");
+  hipLaunchKernelGGL(refnerf_pack_kernel, dim3(1024), dim3(256), 0, as_stream(stream), params, (char*)packed);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_refnerf_trunk_fwd(const void* packed, const float* x, int64_t m, void* save, float* spatial_out,
+                                      int64_t ld, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed && x && save && spatial_out, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && ld >= 256 && ld % 4 == 0 && ((uintptr_t)spatial_out & 15) == 0,
+                 "spatial_out rows must be 16-byte aligned (ld a multiple of 4, >= 256)");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = nerf_tiles_for(m);
+  int rc = set_lds(refnerf_trunk_fwd_kernel, kRefLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(refnerf_trunk_fwd_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
+                     (const char*)packed, x, m, n_tiles, (char*)save, spatial_out, ld);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_refnerf_normal_pass(const void* packed, const void* save, const float* x, int64_t m, void* cdump,
+                                        float* nraw, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed && save && x && cdump && nraw, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = nerf_tiles_for(m);
+  int rc = set_lds(refnerf_normal_kernel, kRefLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(refnerf_normal_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
+                     (const char*)packed, (const char*)save, x, m, n_tiles, (char*)cdump, nraw);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+// the ten weight-gradient problems of the trunk: Dense_1..8 (hidden x hidden), Dense_0 and the x_emb rows of Dense_5
+static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int do_bias, float* grads, hipStream_t st) {
+  WgradArgs a;
+  a.n_problems = 0;
+  int first = 0;
+  auto add = [&](int shape, int xs, int ys, int dense, int row_map, int row_off, int bias, int blocks) {
+    WgradProblem p;
+    p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
+    p.col_map = COL_256; p.do_bias = bias;
+    int64_t nb = blocks;
+    const int64_t cap = (n_tiles + 5) / 6;
+    if (nb > cap) nb = cap;
+    p.first_block = first;
+    p.n_blocks = (int)nb;
+    first += (int)nb;
+    a.p[a.n_problems++] = p;
+  };
+  for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, do_bias, 56);
+  add(2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, do_bias, 32);
+  add(2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, 0, 32);
+  return launch_nerf_wgrad(a, first, xbuf, ybuf, n_tiles, grads, st);
+}
+
+extern "C" int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, const float* g_spatial, int64_t ld,
+                                      int64_t m, void* scratch, float* grads, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed && save && g_spatial && scratch && grads, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && ld >= 256 && ld % 4 == 0 && ((uintptr_t)g_spatial & 15) == 0,
+                 "gradient rows must be 16-byte aligned (ld a multiple of 4, >= 256)");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = nerf_tiles_for(m);
+  int rc = set_lds(refnerf_trunk_bwd_chain_kernel, kRefLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(refnerf_trunk_bwd_chain_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
+                     (const char*)packed, (const char*)save, g_spatial, ld, m, n_tiles, (char*)scratch);
+  LNRF_LAUNCH_CHECK();
+  return trunk_wgrad(save, scratch, n_tiles, 1, grads, as_stream(stream));
+}
+
+extern "C" int lnrf_refnerf_normal_bwd(const void* packed, const void* save, const void* cdump, const float* x,
+                                       const float* u, int64_t m, void* scratch, float* grads, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed && save && cdump && x && u && scratch && grads, "null pointer");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = nerf_tiles_for(m);
+  int rc = set_lds(refnerf_tangent_kernel, kRefLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(refnerf_tangent_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
+                     (const char*)packed, (const char*)save, x, u, m, n_tiles, (char*)scratch);
+  LNRF_LAUNCH_CHECK();
+  return trunk_wgrad(scratch, cdump, n_tiles, 0, grads, as_stream(stream));
+}

@@ -77,6 +77,12 @@ PROTOTYPES = {
                                         c_int64, _P, _P]),
     "lnrf_refnerf_color_fwd": (c_int32, [_P, _P, _P, c_int64, _P, _P]),
     "lnrf_refnerf_color_bwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "lnrf_refnerf_trunk_packed_bytes": (c_int64, []),
+    "lnrf_refnerf_trunk_pack": (c_int32, [_P, _P, _P]),
+    "lnrf_refnerf_trunk_fwd": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P]),
+    "lnrf_refnerf_normal_pass": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_refnerf_trunk_bwd": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P]),
+    "lnrf_refnerf_normal_bwd": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "lnrf_nerf_param_count": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_packed_bytes": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_save_bytes": (c_int64, [POINTER(NerfShape), c_int64]),

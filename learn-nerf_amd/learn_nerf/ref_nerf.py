@@ -2,14 +2,19 @@
 learn_nerf.ref_nerf — RefNERFBase, RefNERFModel, linear_rgb_to_srgb, integrated_directional_encoding,
 spherical_harmonic, HARMONIC_COUNTS, REF_NERF_OUT_DIM (reference: learn_nerf/ref_nerf.py).
 
-Spatial / directional blocks run on the exact-fp32 dense kernels (dense.hip), the per-sample head
-(normals, reflection, integrated directional encoding, diffuse + specular, sRGB, aux losses) and the
-embedding derivative maps are HIP kernels (refnerf.hip).  The analytic normal -d out[:,0]/dx
-(ref_nerf.py:38-43) is an explicit input-gradient pass; because it enters the training loss
-(normal_mse, ref_nerf.py:73), backward() also runs the second-order ("double backward") chain.
+The per-sample head (normals, reflection, integrated directional encoding, diffuse + specular, sRGB, aux
+losses) and the embedding derivative maps are HIP kernels (refnerf.hip); the 273 -> 128 -> 3 directional block
+runs on the dense GEMM kernels (dense.hip).  The analytic normal -d out[:,0]/dx (ref_nerf.py:38-43) is an explicit
+input-gradient pass; because it enters the training loss (normal_mse, ref_nerf.py:73), backward() also runs the
+second-order ("double backward") chain.  The spatial block — 94 % of the FLOPs — has two implementations:
+  precision="bf16", default widths: the fused bf16-MFMA chain kernels of refnerf_fused.hip (trunk forward, normal
+      pass, first- and second-order backward with the shared weight-gradient kernel);
+  precision="fp32" or any other shape: the generic dense GEMM path (exact fp32 / bf16 operands), layer by layer.
 """
-from dataclasses import dataclass
-from typing import Dict, List, Tuple
+import ctypes
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Tuple
 
 import torch
 
@@ -61,6 +66,36 @@ class RefNERFModel(RefNERFBase):
     d_freqs: int = 4  # unused, as in the reference
     precision: str = "bf16"  # operands of the Dense layers: "bf16" (MFMA rate) | "fp32" (exact, parity gate)
     tag: str = "refnerf"
+    spatial_kernel: str = "fused"  # bf16 + default widths: "fused" chain kernels | "dense" GEMM path
+
+    _pack_cache: Any = field(default=None, repr=False, compare=False)
+    _pack_generation: int = field(default=0, repr=False, compare=False)
+
+    def invalidate_packed(self) -> None:
+        """Call after the parameters were modified outside torch (e.g. by lnrf_adam_step)."""
+        self._pack_generation += 1
+
+    def _use_fused_trunk(self) -> bool:
+        return (self.precision == "bf16" and self.spatial_kernel == "fused"
+                and (self.input_layers, self.mid_layers, self.hidden_dim, self.x_freqs) == (5, 4, 256, 10))
+
+    def packed_trunk(self, flat: torch.Tensor) -> torch.Tensor:
+        """Fragment streams of Dense_0..8 for the fused trunk kernels; same cache discipline as
+        NeRFModel.packed_weights (fresh buffer per miss, entries keep their source tensor alive)."""
+        if self._pack_cache is None:
+            self._pack_cache = OrderedDict()
+        key = (flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
+        hit = self._pack_cache.get(key)
+        if hit is not None:
+            self._pack_cache.move_to_end(key)
+            return hit[1]
+        packed = torch.empty(L.lib().lnrf_refnerf_trunk_packed_bytes(), dtype=torch.uint8, device=flat.device)
+        L.check(L.lib().lnrf_refnerf_trunk_pack(L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
+                "refnerf_trunk_pack")
+        self._pack_cache[key] = (flat, packed)
+        while len(self._pack_cache) > 4:
+            self._pack_cache.popitem(last=False)
+        return packed
 
     def layer_dims(self) -> List[Tuple[int, int]]:
         xe = 6 * self.x_freqs
@@ -99,9 +134,90 @@ class RefNERFModel(RefNERFBase):
             out.append((k, b))
         return out
 
+    # ---- fused spatial block ---------------------------------------------------------------------------
+    def _fused_forward_points(self, flat, x, d, save: bool):
+        lib = L.lib()
+        W = self._views(flat)
+        m, dev, hd = x.shape[0], flat.device, self.hidden_dim
+        ne = self.sh_degree ** 2
+        ns = self.input_layers + self.mid_layers
+        packed = self.packed_trunk(flat)
+        shape = L.NerfShape(5, 4, 256, 128, 10, 4)  # the trunk's buffers have NeRFModel's layout
+        save_buf = torch.empty(lib.lnrf_nerf_save_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+        cdump = torch.empty(lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+        width = hd + ne + 1
+        ld = (width + 3) // 4 * 4  # rows 16-byte aligned for the fused kernels' float4 accesses
+        dir_full = torch.empty((m, ld), dtype=F32, device=dev)
+        dir_in = dir_full[:, :width]  # [spatial_out, IDE, -d.n] (ref_nerf.py:63)
+        nraw = torch.empty((m, 3), dtype=F32, device=dev)
+        with _prof.section(f"{self.tag}_spatial_fwd"):
+            L.check(lib.lnrf_refnerf_trunk_fwd(L.ptr(packed, torch.uint8), L.ptr(x), m, L.ptr(save_buf, torch.uint8),
+                                               L.ptr(dir_full), ld, L.stream()), "refnerf_trunk_fwd")
+        with _prof.section(f"{self.tag}_normal_pass"):
+            L.check(lib.lnrf_refnerf_normal_pass(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8), L.ptr(x), m,
+                                                 L.ptr(cdump, torch.uint8), L.ptr(nraw), L.stream()),
+                    "refnerf_normal_pass")
+        with _prof.section(f"{self.tag}_head_fwd"), ops.dense_precision(self.precision):
+            density, diffuse, spectral, aux2 = ops.refnerf_head_fwd(dir_in, nraw, d, self.sh_degree, dir_in[:, hd:])
+            hcol = ops.dense_fwd(dir_in, W[ns][0], W[ns][1], L.ACT_RELU)  # ref_nerf.py:105-107
+            dir_out = ops.dense_fwd(hcol, W[ns + 1][0], W[ns + 1][1], L.ACT_NONE)
+            rgb = ops.refnerf_color_fwd(dir_out, spectral, diffuse)
+        aux = dict(normal_mse=aux2[:, 0], neg_normal=aux2[:, 1])
+        ctx = None
+        if save:
+            ctx = dict(kind="fused", flat=flat, packed=packed, x=x, d=d, save=save_buf, cdump=cdump, dir_in=dir_in,
+                       ld=ld, nraw=nraw, density=density, diffuse=diffuse, spectral=spectral, hcol=hcol,
+                       dir_out=dir_out)
+        return density, rgb, aux, ctx
+
+    def _fused_backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+        lib = L.lib()
+        W = self._views(ctx["flat"])
+        G = self._views(grad_flat)
+        x, d, dir_in, ld = ctx["x"], ctx["d"], ctx["dir_in"], ctx["ld"]
+        m, dev, hd = x.shape[0], grad_flat.device, self.hidden_dim
+        ns = self.input_layers + self.mid_layers
+        packed, save_buf, cdump = ctx["packed"], ctx["save"], ctx["cdump"]
+        if g_aux is None:
+            g_aux2 = torch.zeros((m, 2), dtype=F32, device=dev)
+        else:
+            g_aux2 = torch.stack([g_aux["normal_mse"].reshape(-1), g_aux["neg_normal"].reshape(-1)], 1).contiguous()
+        with _prof.section(f"{self.tag}_head_bwd"), ops.dense_precision(self.precision):
+            g_do, g_sp, g_df = ops.refnerf_color_bwd(ctx["dir_out"], ctx["spectral"], ctx["diffuse"],
+                                                     g_rgb.reshape(-1, 3).contiguous())
+            ops.dense_bwd_weight(ctx["hcol"], g_do, G[ns + 1][0], G[ns + 1][1])
+            gy = ops.dense_bwd_input(g_do, W[ns + 1][0], gate=ctx["hcol"])
+            ops.dense_bwd_weight(dir_in, gy, G[ns][0], G[ns][1])
+            g_full = torch.empty((m, ld), dtype=F32, device=dev)
+            g_dir_in = ops.dense_bwd_input(gy, W[ns][0], out=g_full[:, :dir_in.shape[1]])
+            u = ops.refnerf_head_bwd(dir_in, ctx["nraw"], d, self.sh_degree, g_density.reshape(-1).contiguous(), g_df,
+                                     g_sp, g_dir_in[:, hd:], g_aux2, g_dir_in)
+        shape = L.NerfShape(5, 4, 256, 128, 10, 4)
+        with _prof.section(f"{self.tag}_spatial_bwd"):  # first-order: d L / d spatial_out -> Dense_8 .. Dense_0
+            scratch = torch.empty(lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+            L.check(lib.lnrf_refnerf_trunk_bwd(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8), L.ptr(g_full),
+                                               ld, m, L.ptr(scratch, torch.uint8), L.ptr(grad_flat), L.stream()),
+                    "refnerf_trunk_bwd")
+        with _prof.section(f"{self.tag}_normal_bwd"):  # second-order: through n_raw (u = d L / d n_raw)
+            tscratch = torch.empty(lib.lnrf_nerf_save_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+            L.check(lib.lnrf_refnerf_normal_bwd(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8),
+                                                L.ptr(cdump, torch.uint8), L.ptr(x), L.ptr(u), m,
+                                                L.ptr(tscratch, torch.uint8), L.ptr(grad_flat), L.stream()),
+                    "refnerf_normal_bwd")
+
     # ---- forward ------------------------------------------------------------------------------------
-    @ops.uses_model_precision
     def forward_points(self, flat, x, d, save: bool):
+        if self._use_fused_trunk():
+            return self._fused_forward_points(flat, x, d, save)
+        return self._dense_forward_points(flat, x, d, save)
+
+    def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+        if ctx.get("kind") == "fused":
+            return self._fused_backward(ctx, g_density, g_rgb, g_aux, grad_flat)
+        return self._dense_backward(ctx, g_density, g_rgb, g_aux, grad_flat)
+
+    @ops.uses_model_precision
+    def _dense_forward_points(self, flat, x, d, save: bool):
         W = self._views(flat)
         m, dev, hd = x.shape[0], flat.device, self.hidden_dim
         xe_w, ne = 6 * self.x_freqs, self.sh_degree ** 2
@@ -155,7 +271,7 @@ class RefNERFModel(RefNERFBase):
 
     # ---- backward -------------------------------------------------------------------------------------
     @ops.uses_model_precision
-    def backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
+    def _dense_backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
         W = self._views(ctx["flat"])
         G = self._views(grad_flat)
         x, d, cat_x, dir_in, h, c = ctx["x"], ctx["d"], ctx["cat_x"], ctx["dir_in"], ctx["h"], ctx["c"]
