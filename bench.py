@@ -153,6 +153,40 @@ def ngp_roofline(fams, m_c, m_f):
                 frac=round(hg[dom]["GBps"] / 8000.0, 4), traffic=None)
 
 
+# RefNERFModel, MACs per evaluation (ref_nerf.py:92-107 widths): trunk Dense_0..8 = 60*256 + 4*256^2 + 316*256 + 3*256^2
+REF_TRUNK_MAC = 60 * 256 + 4 * 65536 + 316 * 256 + 3 * 65536   # 555,008: forward, = normal pass, = weight gradients
+REF_TRUNK_DGRAD_MAC = 8 * 65536                                  # 524,288: first-order input-gradient chain
+REF_TANGENT_MAC = REF_TRUNK_MAC - 65536                          # 489,472: second-order tangent chain (Dense_0..7)
+REF_DIR_MAC = 273 * 128 + 128 * 3                                # 35,328: directional block, x3 (fwd, dgrad, wgrad)
+REF_STEP_MAC = (2 * REF_TRUNK_MAC + (REF_TRUNK_DGRAD_MAC + REF_TRUNK_MAC) + (REF_TANGENT_MAC + REF_TRUNK_MAC)
+                + 3 * REF_DIR_MAC)                               # 3,339,776 MAC = 6.68 MFLOP per evaluation
+
+
+def refnerf_roofline(fams, n, ms_step):
+    """configs[3] is MFMA-bound like configs[1]: algorithmic FLOP of the dominant fused kernel family / its HIP-event
+    time / bf16 peak, and the whole step's algorithmic FLOP rate."""
+    flop = {"_spatial_fwd": 2 * REF_TRUNK_MAC, "_normal_pass": 2 * REF_TRUNK_MAC,
+            "_spatial_bwd": 2 * (REF_TRUNK_DGRAD_MAC + REF_TRUNK_MAC), "_normal_bwd": 2 * (REF_TANGENT_MAC + REF_TRUNK_MAC)}
+    best = None
+    for name, v in fams.items():
+        m = n * (COARSE if name.startswith("coarse") else COARSE + FINE)
+        for suffix, per_eval in flop.items():
+            if name.endswith(suffix):
+                v["tflops"] = round(m * per_eval / (v["ms"] * 1e-3) / 1e12, 1)
+                if best is None or v["ms"] > fams[best]["ms"]:
+                    best = name
+    roofline = None
+    if best is not None:
+        roofline = dict(bound="mfma", kernel=best, achieved=fams[best]["tflops"], peak=PEAK_BF16_FLOPS / 1e12,
+                        unit="TFLOP/s", frac=round(fams[best]["tflops"] / (PEAK_BF16_FLOPS / 1e12), 4), traffic=None,
+                        ms_per_launch=fams[best]["ms"],
+                        note="dominant fused-trunk kernel family (chain + weight-gradient launches)")
+    tf = n * (COARSE + COARSE + FINE) * 2 * REF_STEP_MAC / (ms_step * 1e-3) / 1e12
+    step = dict(achieved=round(tf, 1), peak=PEAK_BF16_FLOPS / 1e12, unit="TFLOP/s", frac=round(tf / (PEAK_BF16_FLOPS / 1e12), 4),
+                note="whole step: 6,679,552 algorithmic FLOP per model evaluation incl. the second-order normal term")
+    return roofline, step
+
+
 def short_leg(workload, n, device, table_log2, steps=10, warmup=3):
     """A few steps of another BASELINE config on this GPU (N = 1 only), so that the driver's record covers it."""
     from learn_nerf import _prof
@@ -182,7 +216,7 @@ def short_leg(workload, n, device, table_log2, steps=10, warmup=3):
         out["roofline"] = ngp_roofline(fams, n * COARSE, n * (COARSE + FINE))
         out["config"] = f"instant_ngp hash-grid L=6/16, T=2^{table_log2} (BASELINE configs[2])"
     else:
-        out["roofline"] = None  # generic GEMM chain, no fused kernel yet: no roofline model
+        out["roofline"], out["step_mfma"] = refnerf_roofline(fams, n, ms)
         out["config"] = "ref_nerf.py RefNERFModel sh_degree 4 incl. normal losses (BASELINE configs[3])"
     out["kernels"] = fams
     del loop, step
@@ -199,7 +233,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="nerf", choices=["nerf", "ngp", "refnerf"],
                     help="nerf = BASELINE configs[1] (the metric's config, default); ngp = configs[2] hash-grid path; "
-                         "refnerf = configs[3] RefNERFModel on the generic dense path (no roofline model: reported as null)")
+                         "refnerf = configs[3] RefNERFModel (fused spatial block)")
     ap.add_argument("--table_log2", type=int, default=19, help="ngp: log2 of the hash table size (configs[2]: 19)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -309,6 +343,8 @@ def main():
         timed = {k: v for k, v in fams.items() if v["tflops"] is not None}
         if args.workload == "ngp":
             roofline = ngp_roofline(fams, m_c, m_f)
+        elif args.workload == "refnerf":
+            roofline, ref_step = refnerf_roofline(fams, n, ms_per_step)
         elif timed:
             # Design HBM bytes per 32-evaluation tile of each kernel family:
             # forward writes the 167 KiB save block, the backward chain reads 9 KiB of masks and writes
@@ -364,7 +400,9 @@ def main():
             kernels=fams,
             losses={k: round(float(v), 5) for k, v in log.items()},
         )
-        if args.workload != "nerf":
+        if args.workload == "refnerf":
+            out["step_mfma"] = ref_step
+        elif args.workload != "nerf":
             del out["step_mfma"]  # the FLOP model is the vanilla NeRFModel's; the hash-grid step is gather/scatter bound
         if args.workload == "nerf" and args.precision == "bf16":
             # the render path: the fused forward without activation dumps, plain bf16 and split precision

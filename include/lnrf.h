@@ -382,6 +382,18 @@ int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, const float* g_
                            void* scratch, float* grads, lnrf_stream_t stream);
 int lnrf_refnerf_normal_bwd(const void* packed, const void* save, const void* cdump, const float* x,
                             const float* u, int64_t m, void* scratch, float* grads, lnrf_stream_t stream);
+/* Directional block of RefNERFModel (ref_nerf.py:100-107: Dense_9 273 -> 128 relu, Dense_10 128 -> 3; sh_degree 4,
+ * color_layer_dim 128), fused like the trunk (the same `packed` blob carries its streams).
+ *   lnrf_refnerf_dir_fwd   dir_out[m, 3] (pre-sigmoid) from dir_in[m, 0:273] = [spatial_out, IDE, -d.n] (fp32, `ld` >=
+ *                          276 floats per row, rows 16-byte aligned); dsave: lnrf_refnerf_dir_save_bytes(m)
+ *   lnrf_refnerf_dir_bwd   g_dir_in[m, 0:273] = d L / d dir_in (overwritten) and grads += d L / d Dense_9, Dense_10 given
+ *                          g_dir_out[m, 3]; scratch: lnrf_refnerf_dir_scratch_bytes(m) */
+int64_t lnrf_refnerf_dir_save_bytes(int64_t m);
+int64_t lnrf_refnerf_dir_scratch_bytes(int64_t m);
+int lnrf_refnerf_dir_fwd(const void* packed, const float* dir_in, int64_t ld, int64_t m, void* dsave,
+                         float* dir_out, lnrf_stream_t stream);
+int lnrf_refnerf_dir_bwd(const void* packed, const void* dsave, const float* g_dir_out, int64_t m, void* scratch,
+                         float* g_dir_in, int64_t ld, float* grads, lnrf_stream_t stream);
 
 /* ------------------------------------------------------- data-parallel exchange ---- */
 

@@ -155,7 +155,7 @@ __device__ __forceinline__ void bwd_chain_tile(RING& ring, SINK& sink, const cha
 // weight-gradient problems  dW_l[in][out] += sum_m X_l[m][in] * dy_l[m][out]
 // ---------------------------------------------------------------------------------------------
 enum { ROW_HIDDEN = 0, ROW_XEMB = 1, ROW_DEMB = 2 };
-enum { COL_256 = 0, COL_DY10M = 1, COL_DY11 = 2 };
+enum { COL_256 = 0, COL_DY10M = 1, COL_DY11 = 2, COL_EXPLICIT = 3 };
 struct WgradProblem {
   int shape;     // operand-shape body, see nerf_wgrad_kernel
   int x_slot0;   // first X slot in the forward save buffer
@@ -166,6 +166,9 @@ struct WgradProblem {
   int col_map;
   int do_bias;
   int first_block, n_blocks;
+  // COL_EXPLICIT (kernels outside NeRFModel's parameter layout, e.g. RefNERFModel's directional block): float offsets
+  // of the kernel / bias in the gradient vector, kernel columns, and number of real kernel rows
+  int w_off, b_off, out_dim, n_rows;
 };
 constexpr int kMaxProblems = 13;
 struct WgradArgs {
@@ -183,6 +186,12 @@ struct NerfWgradEpi {
       else if (colr == 0 && pb.row_map == ROW_HIDDEN) { out_idx = 0; out_dim = 1; dense_w = 9; }
     } else if (pb.col_map == COL_DY11) {
       if (colr < 3) { out_idx = colr; out_dim = 3; }
+    } else if (pb.col_map == COL_EXPLICIT) {
+      if (32 * ot + colr < pb.out_dim) out_idx = 32 * ot + colr;
+      out_dim = pb.out_dim;
+      w_off = pb.w_off;
+      b_off = pb.b_off;
+      return;
     } else {
       out_idx = 32 * ot + colr; out_dim = 256;
     }
@@ -192,8 +201,10 @@ struct NerfWgradEpi {
   static __device__ __forceinline__ int row(const WgradProblem& pb, int f, int r16) {
     const int sh = (r16 >> 2) & 1, sj = 4 * (r16 >> 3) + (r16 & 3);  // slot (h, j) of that feature
     int in_idx;
-    if (pb.row_map == ROW_HIDDEN) in_idx = 16 * f + r16;
-    else if (pb.row_map == ROW_XEMB) in_idx = xemb_feat(f, sh, sj);
+    if (pb.row_map == ROW_HIDDEN) {
+      in_idx = 16 * f + r16;
+      if (pb.col_map == COL_EXPLICIT && in_idx >= pb.n_rows) in_idx = -1;
+    } else if (pb.row_map == ROW_XEMB) in_idx = xemb_feat(f, sh, sj);
     else in_idx = demb_feat(f, sh, sj);
     return in_idx >= 0 ? in_idx + pb.row_off : -1;
   }
@@ -214,6 +225,7 @@ static inline int build_wgrad_problems(WgradArgs& a, const int (&blocks)[13], in
     WgradProblem p;
     p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
     p.col_map = col_map; p.do_bias = do_bias;
+    p.w_off = p.b_off = p.out_dim = p.n_rows = 0;
     int64_t nb = blocks[a.n_problems];
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;

@@ -260,9 +260,57 @@ constexpr int64_t kPackFwdOff = 0;
 constexpr int64_t kPackBwdOff = (int64_t)kFwdFrags * kFragBytes;
 constexpr int64_t kPackBiasOff = kPackBwdOff + (int64_t)kBwdFrags * kFragBytes;
 constexpr int64_t kPackBytes = kPackBiasOff + round_up(kBiasFloats * 4, 1024);
-// Ref-NeRF trunk blob: the NeRFModel blob (head layers zero) followed by the normal-pass stream
+// ---- Ref-NeRF directional block (ref_nerf.py:100-107: Dense_9 273 -> 128 relu, Dense_10 128 -> 3) -------------------
+// Input row = [spatial_out(256), IDE(16), -d.n(1)]; k slot (ks, h, j) of its 18 k-steps <-> input feature
+// hidden_feat(ks, h, j) (valid below 273).  Forward stream: Dense_9 (4 out tiles x 18 k-steps, padded to 80
+// fragments), Dense_10 (1 x 8, padded to 16).  Transposed stream: Dense_10^T (4 out tiles x 1 k-step, k slot
+// (h 0, j < 3) = colour channel; padded to 16), Dense_9^T (9 out tiles = 288 >= 273 input rows, 8 k-steps; 72 -> 80).
+constexpr int kDirIn = 273, kDirHidden = 128;
+constexpr int kDirW9 = dense_w_off(9);                       // RefNERFModel's Dense_9 starts where NeRFModel's does
+constexpr int kDirB9 = kDirW9 + kDirIn * kDirHidden;
+constexpr int kDirW10 = kDirB9 + kDirHidden;
+constexpr int kDirB10 = kDirW10 + kDirHidden * 3;
+constexpr int kDirFwdFrags = 96, kDirBwdFrags = 96, kDirBiasFloats = 160;  // bias: 128 + 32 (3 real)
+NL_HD constexpr int dir_fwd_seq(int c) { return c < 72 ? c : 80 + (c - 72); }  // 80 consumed fragments
+NL_HD constexpr int dir_bwd_seq(int c) { return c < 4 ? c : 16 + (c - 4); }    // 76 consumed fragments
+NL_HD constexpr int dir_fwd_weight_index(int g, int lane, int j) {
+  const int r = lane & 31, h = lane >> 5;
+  if (g < 72) {  // Dense_9: out tile o, k-step ks
+    const int o = g / 18, ks = g % 18;
+    const int in = hidden_feat(ks, h, j);
+    return in < kDirIn ? kDirW9 + in * kDirHidden + 32 * o + r : -1;
+  }
+  if (g >= 80 && g < 88) {  // Dense_10
+    if (r >= 3) return -1;
+    return kDirW10 + hidden_feat(g - 80, h, j) * 3 + r;
+  }
+  return -1;
+}
+NL_HD constexpr int dir_bwd_weight_index(int g, int lane, int j) {
+  const int r = lane & 31, h = lane >> 5;
+  if (g < 4) {  // Dense_10^T: rows = hidden feature 32 g + r, k = colour channel
+    if (h != 0 || j >= 3) return -1;
+    return kDirW10 + (32 * g + r) * 3 + j;
+  }
+  if (g >= 16 && g < 88) {  // Dense_9^T: rows = input feature, k = hidden feature
+    const int o = (g - 16) / 8, ks = (g - 16) % 8;
+    const int in = 32 * o + r;
+    return in < kDirIn ? kDirW9 + in * kDirHidden + hidden_feat(ks, h, j) : -1;
+  }
+  return -1;
+}
+NL_HD constexpr int dir_bias_index(int i) { return i < 128 ? kDirB9 + i : (i < 131 ? kDirB10 + (i - 128) : -1); }
+// saved by the directional forward ([slot][tile][1 KiB]): the 18 input fragments, relu(Dense_9) (8), its mask (1)
+constexpr int kDirSaveXin = 0, kDirSaveH = 18, kDirSaveMask = 26, kDirSaveSlots = 27;
+// dumped by the directional backward: dy10 (2 slots, second zero) then dy9 (8 slots)
+constexpr int kDirGradDy10 = 0, kDirGradDy9 = 2, kDirGradSlots = 10;
+
+// Ref-NeRF blob: the NeRFModel blob (head layers zero), the normal-pass stream, the directional block
 constexpr int64_t kRefPackNrmOff = kPackBytes;
-constexpr int64_t kRefPackBytes = kRefPackNrmOff + (int64_t)kNrmFrags * kFragBytes;
+constexpr int64_t kRefPackDirFwdOff = kRefPackNrmOff + (int64_t)kNrmFrags * kFragBytes;
+constexpr int64_t kRefPackDirBwdOff = kRefPackDirFwdOff + (int64_t)kDirFwdFrags * kFragBytes;
+constexpr int64_t kRefPackDirBiasOff = kRefPackDirBwdOff + (int64_t)kDirBwdFrags * kFragBytes;
+constexpr int64_t kRefPackBytes = kRefPackDirBiasOff + 1024;
 
 // ---- saved activations / gradient dumps -------------------------------------------------------
 // Both buffers are [slot][tile][1 KiB]; a slot is one k-step (16 features) of one tensor.

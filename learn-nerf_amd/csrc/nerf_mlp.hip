@@ -462,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
     case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
     case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
     case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
+    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;  // Ref-NeRF Dense_9
     default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
   }
 }

@@ -409,6 +409,142 @@ __global__ __launch_bounds__(kThreads) void refnerf_tangent_kernel(
   hidden(std::integral_constant<int, 7>{}, a0, a1);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// directional block (ref_nerf.py:100-107): dir_out = Dense_10(relu(Dense_9([spatial_out, IDE, -d.n])))
+// One wave = 32 evaluations; the input row (fp32, written by the trunk forward and the head kernel) is converted to
+// bf16 fragments in registers; saves the input fragments, relu(Dense_9) and its mask for the backward.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDirLds = kRingBytes + 1024;
+struct DirFwdSeq {
+  static constexpr int count = 80;
+  static constexpr int at(int c) { return dir_fwd_seq(c); }
+};
+struct DirBwdSeq {
+  static constexpr int count = 76;
+  static constexpr int at(int c) { return dir_bwd_seq(c); }
+};
+
+__global__ __launch_bounds__(kThreads) void refnerf_dir_fwd_kernel(
+    const char* __restrict__ packed, const float* __restrict__ dir_in, int64_t ld, int64_t M, int64_t n_tiles,
+    char* __restrict__ dsave, float* __restrict__ dir_out) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  {
+    const float* bias_g = reinterpret_cast<const float*>(packed + kRefPackDirBiasOff);
+    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
+    for (int i = tid; i < kDirBiasFloats; i += kThreads) bias_l[i] = bias_g[i];
+  }
+  // input fragments: k slot (ks, h, j) <-> feature 16 ks + 8 (j >> 2) + 4 h + (j & 3); features >= 273 are zero
+  bf16x8 xin[18];
+  static_for<18>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    float4 lo = make_float4(0, 0, 0, 0), hi = make_float4(0, 0, 0, 0);
+    if (valid) {
+      const float* row = dir_in + m * ld + 16 * ks + 4 * h;
+      if constexpr (ks < 17) {
+        lo = *reinterpret_cast<const float4*>(row);
+        hi = *reinterpret_cast<const float4*>(row + 8);
+      } else {
+        if (h == 0) lo.x = row[0];  // feature 272 = -d.n; 273.. do not exist
+      }
+    }
+    xin[ks][0] = (__bf16)lo.x; xin[ks][1] = (__bf16)lo.y; xin[ks][2] = (__bf16)lo.z; xin[ks][3] = (__bf16)lo.w;
+    xin[ks][4] = (__bf16)hi.x; xin[ks][5] = (__bf16)hi.y; xin[ks][6] = (__bf16)hi.z; xin[ks][7] = (__bf16)hi.w;
+  });
+  __syncthreads();
+  Ring<kDirFwdFrags / kStageFrags, DirFwdSeq> ring;
+  ring.stream = packed + kRefPackDirFwdOff;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+  DumpAddr dump{dsave, n_tiles, tile, c, h};
+  static_for<18>([&](auto i) { stream_store(dump.at(kDirSaveXin + decltype(i)::value), frag_to_bits(xin[decltype(i)::value])); });
+  bf16x8 hcol[8];
+  unsigned mask_bits[2] = {0u, 0u};
+  chain_layer<0, 18, 4>(
+      ring, [&](auto o_) { return bias_acc(32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 { return xin[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        hcol[2 * o] = acc_to_frag<0, true>(acc);
+        hcol[2 * o + 1] = acc_to_frag<1, true>(acc);
+        stream_store(dump.at(kDirSaveH + 2 * o), frag_to_bits(hcol[2 * o]));
+        stream_store(dump.at(kDirSaveH + 2 * o + 1), frag_to_bits(hcol[2 * o + 1]));
+        mask_bits[o >> 1] |= relu_bits(hcol[2 * o], hcol[2 * o + 1]) << (16 * (o & 1));
+      });
+  *reinterpret_cast<uint4*>(dsave + ((int64_t)kDirSaveMask * n_tiles + tile) * kFragBytes + lane * 16) =
+      make_uint4(mask_bits[0], mask_bits[1], 0u, 0u);
+  chain_layer<72, 8, 1>(
+      ring, [&](auto) { return bias_acc(128, h); }, [&](auto k_) -> bf16x8 { return hcol[decltype(k_)::value]; },
+      [&](auto, const f32x16& acc) {
+        if (h == 0 && valid) {
+          dir_out[m * 3 + 0] = acc[0];
+          dir_out[m * 3 + 1] = acc[1];
+          dir_out[m * 3 + 2] = acc[2];
+        }
+      });
+}
+
+// backward: g_dir_out [M,3] -> dy10, dy9 dumps (weight gradients) and g_dir_in [M, ld] = dy9 Dense_9^T (fp32, all 273 columns)
+__global__ __launch_bounds__(kThreads) void refnerf_dir_bwd_kernel(
+    const char* __restrict__ packed, const char* __restrict__ dsave, const float* __restrict__ g_do, int64_t M,
+    int64_t n_tiles, char* __restrict__ gdump, float* __restrict__ g_dir_in, int64_t ld) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  bf16x8 dy10 = zero_frag();
+  if (valid && h == 0) {
+    dy10[0] = (__bf16)g_do[m * 3 + 0];
+    dy10[1] = (__bf16)g_do[m * 3 + 1];
+    dy10[2] = (__bf16)g_do[m * 3 + 2];
+  }
+  const uint4 mk = *reinterpret_cast<const uint4*>(dsave + ((int64_t)kDirSaveMask * n_tiles + tile) * kFragBytes + lane * 16);
+  __syncthreads();
+  Ring<kDirBwdFrags / kStageFrags, DirBwdSeq> ring;
+  ring.stream = packed + kRefPackDirBwdOff;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+  DumpAddr gd{gdump, n_tiles, tile, c, h};
+  stream_store(gd.at(kDirGradDy10), frag_to_bits(dy10));
+  stream_store(gd.at(kDirGradDy10 + 1), frag_to_bits(zero_frag()));
+  bf16x8 dy9[8];
+  chain_layer<0, 1, 4>(
+      ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy10; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        const unsigned mb = (o >> 1) == 0 ? mk.x : mk.y;
+        dy9[2 * o] = masked_frag<0>(acc, mb, 16 * (o & 1));
+        dy9[2 * o + 1] = masked_frag<1>(acc, mb, 16 * (o & 1));
+        stream_store(gd.at(kDirGradDy9 + 2 * o), frag_to_bits(dy9[2 * o]));
+        stream_store(gd.at(kDirGradDy9 + 2 * o + 1), frag_to_bits(dy9[2 * o + 1]));
+      });
+  chain_layer<4, 8, 9>(
+      ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy9[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        if (valid) {
+          float* gr = g_dir_in + m * ld + 32 * o + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            // columns 32 o + 8 g + 4 h .. + 3; the last tile ends at column 272 (the row has ld >= 276 floats)
+            if (32 * o + 8 * g + 4 * h + 3 < (int)ld)
+              *reinterpret_cast<float4*>(gr + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+          }
+        }
+      });
+}
+
 // ---------------------------------------------------------------------------------------------
 // packing: the NeRFModel streams restricted to the trunk (head fragments zero) + the normal-pass stream
 // ---------------------------------------------------------------------------------------------
@@ -416,7 +552,8 @@ __global__ void refnerf_pack_kernel(const float* __restrict__ params, char* __re
   const int64_t total_f = (int64_t)kFwdFrags * 512;
   const int64_t total_b = (int64_t)kBwdFrags * 512;
   const int64_t total_n = (int64_t)kNrmFrags * 512;
-  const int64_t total = total_f + total_b + kBiasFloats + total_n;
+  const int64_t total_d = (int64_t)(kDirFwdFrags + kDirBwdFrags) * 512;
+  const int64_t total = total_f + total_b + kBiasFloats + total_n + total_d + kDirBiasFloats;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     if (e < total_f + total_b) {
@@ -446,6 +583,20 @@ __global__ void refnerf_pack_kernel(const float* __restrict__ params, char* __re
         if (i >= fwd_bias_base(k)) s = k;
       const int idx = s <= 8 ? fwd_bias_index(s, i - fwd_bias_base(s)) : -1;
       reinterpret_cast<float*>(packed + kPackBiasOff)[i] = idx >= 0 ? params[idx] : 0.0f;
+    } else if (e >= total_f + total_b + kBiasFloats + total_n) {  // directional block
+      const int64_t ee = e - (total_f + total_b + kBiasFloats + total_n);
+      if (ee < total_d) {
+        const bool fwd = ee < (int64_t)kDirFwdFrags * 512;
+        const int64_t e2 = fwd ? ee : ee - (int64_t)kDirFwdFrags * 512;
+        const int g = (int)(e2 >> 9), lane = (int)((e2 >> 3) & 63), j = (int)(e2 & 7);
+        const int idx = fwd ? dir_fwd_weight_index(g, lane, j) : dir_bwd_weight_index(g, lane, j);
+        reinterpret_cast<__bf16*>(packed + (fwd ? kRefPackDirFwdOff : kRefPackDirBwdOff))[e2] =
+            (__bf16)(idx >= 0 ? params[idx] : 0.0f);
+      } else {
+        const int i = (int)(ee - total_d);
+        const int idx = dir_bias_index(i);
+        reinterpret_cast<float*>(packed + kRefPackDirBiasOff)[i] = idx >= 0 ? params[idx] : 0.0f;
+      }
     } else {
       const int64_t ee = e - total_f - total_b - kBiasFloats;
       const int g = (int)(ee >> 9), lane = (int)((ee >> 3) & 63), j = (int)(ee & 7);
@@ -519,6 +670,7 @@ static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int 
     WgradProblem p;
     p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
     p.col_map = COL_256; p.do_bias = bias;
+    p.w_off = p.b_off = p.out_dim = p.n_rows = 0;
     int64_t nb = blocks;
     const int64_t cap = (n_tiles + 5) / 6;
     if (nb > cap) nb = cap;
@@ -560,4 +712,56 @@ extern "C" int lnrf_refnerf_normal_bwd(const void* packed, const void* save, con
                      (const char*)packed, (const char*)save, x, u, m, n_tiles, (char*)scratch);
   LNRF_LAUNCH_CHECK();
   return trunk_wgrad(scratch, cdump, n_tiles, 0, grads, as_stream(stream));
+}
+
+extern "C" int64_t lnrf_refnerf_dir_save_bytes(int64_t m) { return (int64_t)kDirSaveSlots * nerf_tiles_for(m) * kFragBytes; }
+extern "C" int64_t lnrf_refnerf_dir_scratch_bytes(int64_t m) { return (int64_t)kDirGradSlots * nerf_tiles_for(m) * kFragBytes; }
+
+extern "C" int lnrf_refnerf_dir_fwd(const void* packed, const float* dir_in, int64_t ld, int64_t m, void* dsave,
+                                    float* dir_out, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed && dir_in && dsave && dir_out, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && ld >= 276 && ld % 4 == 0 && ((uintptr_t)dir_in & 15) == 0,
+                 "dir_in rows must be 16-byte aligned (ld a multiple of 4, >= 276)");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = nerf_tiles_for(m);
+  int rc = set_lds(refnerf_dir_fwd_kernel, kDirLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(refnerf_dir_fwd_kernel, tile_grid(n_tiles), dim3(kThreads), kDirLds, as_stream(stream),
+                     (const char*)packed, dir_in, ld, m, n_tiles, (char*)dsave, dir_out);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_refnerf_dir_bwd(const void* packed, const void* dsave, const float* g_dir_out, int64_t m,
+                                    void* scratch, float* g_dir_in, int64_t ld, float* grads, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed && dsave && g_dir_out && scratch && g_dir_in && grads, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && ld >= 276 && ld % 4 == 0 && ((uintptr_t)g_dir_in & 15) == 0,
+                 "g_dir_in rows must be 16-byte aligned (ld a multiple of 4, >= 276)");
+  if (m == 0) return LNRF_OK;
+  const int64_t n_tiles = nerf_tiles_for(m);
+  int rc = set_lds(refnerf_dir_bwd_kernel, kDirLds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(refnerf_dir_bwd_kernel, tile_grid(n_tiles), dim3(kThreads), kDirLds, as_stream(stream),
+                     (const char*)packed, (const char*)dsave, g_dir_out, m, n_tiles, (char*)scratch, g_dir_in, ld);
+  LNRF_LAUNCH_CHECK();
+  // weight gradients: Dense_9 = [input fragments]^T dy9 (273 x 128 + bias), Dense_10 = relu(Dense_9)^T dy10 (128 x 3 + bias)
+  WgradArgs a;
+  a.n_problems = 0;
+  int first = 0;
+  auto add = [&](int shape, int xs, int ys, int out_dim, int n_rows, int w_off, int b_off, int blocks) {
+    WgradProblem p;
+    p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = 0; p.row_map = ROW_HIDDEN; p.row_off = 0;
+    p.col_map = COL_EXPLICIT; p.do_bias = 1;
+    p.w_off = w_off; p.b_off = b_off; p.out_dim = out_dim; p.n_rows = n_rows;
+    int64_t nb = blocks;
+    const int64_t cap = (n_tiles + 5) / 6;
+    if (nb > cap) nb = cap;
+    p.first_block = first;
+    p.n_blocks = (int)nb;
+    first += (int)nb;
+    a.p[a.n_problems++] = p;
+  };
+  add(5, kDirSaveXin, kDirGradDy9, kDirHidden, kDirIn, kDirW9, kDirB9, 400);
+  add(4, kDirSaveH, kDirGradDy10, 3, kDirHidden, kDirW10, kDirB10, 112);
+  return launch_nerf_wgrad(a, first, dsave, scratch, n_tiles, grads, as_stream(stream));
 }

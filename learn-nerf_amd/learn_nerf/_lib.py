@@ -83,6 +83,10 @@ PROTOTYPES = {
     "lnrf_refnerf_normal_pass": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
     "lnrf_refnerf_trunk_bwd": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P]),
     "lnrf_refnerf_normal_bwd": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_refnerf_dir_save_bytes": (c_int64, [c_int64]),
+    "lnrf_refnerf_dir_scratch_bytes": (c_int64, [c_int64]),
+    "lnrf_refnerf_dir_fwd": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P]),
+    "lnrf_refnerf_dir_bwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P]),
     "lnrf_nerf_param_count": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_packed_bytes": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_save_bytes": (c_int64, [POINTER(NerfShape), c_int64]),

@@ -79,6 +79,10 @@ class RefNERFModel(RefNERFBase):
         return (self.precision == "bf16" and self.spatial_kernel == "fused"
                 and (self.input_layers, self.mid_layers, self.hidden_dim, self.x_freqs) == (5, 4, 256, 10))
 
+    def _use_fused_dir(self) -> bool:
+        """the fused directional-block kernels cover the reference's widths: 256 + 4^2 + 1 -> 128 -> 3"""
+        return self.sh_degree == 4 and self.color_layer_dim == 128
+
     def packed_trunk(self, flat: torch.Tensor) -> torch.Tensor:
         """Fragment streams of Dense_0..8 for the fused trunk kernels; same cache discipline as
         NeRFModel.packed_weights (fresh buffer per miss, entries keep their source tensor alive)."""
@@ -157,17 +161,25 @@ class RefNERFModel(RefNERFBase):
             L.check(lib.lnrf_refnerf_normal_pass(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8), L.ptr(x), m,
                                                  L.ptr(cdump, torch.uint8), L.ptr(nraw), L.stream()),
                     "refnerf_normal_pass")
+        hcol = dsave = None
         with _prof.section(f"{self.tag}_head_fwd"), ops.dense_precision(self.precision):
             density, diffuse, spectral, aux2 = ops.refnerf_head_fwd(dir_in, nraw, d, self.sh_degree, dir_in[:, hd:])
-            hcol = ops.dense_fwd(dir_in, W[ns][0], W[ns][1], L.ACT_RELU)  # ref_nerf.py:105-107
-            dir_out = ops.dense_fwd(hcol, W[ns + 1][0], W[ns + 1][1], L.ACT_NONE)
+            if self._use_fused_dir():  # ref_nerf.py:105-107 on the fused chain
+                dsave = torch.empty(lib.lnrf_refnerf_dir_save_bytes(m), dtype=torch.uint8, device=dev)
+                dir_out = torch.empty((m, 3), dtype=F32, device=dev)
+                L.check(lib.lnrf_refnerf_dir_fwd(L.ptr(packed, torch.uint8), L.ptr(dir_full), ld, m,
+                                                 L.ptr(dsave, torch.uint8), L.ptr(dir_out), L.stream()),
+                        "refnerf_dir_fwd")
+            else:
+                hcol = ops.dense_fwd(dir_in, W[ns][0], W[ns][1], L.ACT_RELU)
+                dir_out = ops.dense_fwd(hcol, W[ns + 1][0], W[ns + 1][1], L.ACT_NONE)
             rgb = ops.refnerf_color_fwd(dir_out, spectral, diffuse)
         aux = dict(normal_mse=aux2[:, 0], neg_normal=aux2[:, 1])
         ctx = None
         if save:
             ctx = dict(kind="fused", flat=flat, packed=packed, x=x, d=d, save=save_buf, cdump=cdump, dir_in=dir_in,
                        ld=ld, nraw=nraw, density=density, diffuse=diffuse, spectral=spectral, hcol=hcol,
-                       dir_out=dir_out)
+                       dir_out=dir_out, dsave=dsave)
         return density, rgb, aux, ctx
 
     def _fused_backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
@@ -185,11 +197,18 @@ class RefNERFModel(RefNERFBase):
         with _prof.section(f"{self.tag}_head_bwd"), ops.dense_precision(self.precision):
             g_do, g_sp, g_df = ops.refnerf_color_bwd(ctx["dir_out"], ctx["spectral"], ctx["diffuse"],
                                                      g_rgb.reshape(-1, 3).contiguous())
-            ops.dense_bwd_weight(ctx["hcol"], g_do, G[ns + 1][0], G[ns + 1][1])
-            gy = ops.dense_bwd_input(g_do, W[ns + 1][0], gate=ctx["hcol"])
-            ops.dense_bwd_weight(dir_in, gy, G[ns][0], G[ns][1])
             g_full = torch.empty((m, ld), dtype=F32, device=dev)
-            g_dir_in = ops.dense_bwd_input(gy, W[ns][0], out=g_full[:, :dir_in.shape[1]])
+            if ctx["dsave"] is not None:
+                dscratch = torch.empty(lib.lnrf_refnerf_dir_scratch_bytes(m), dtype=torch.uint8, device=dev)
+                L.check(lib.lnrf_refnerf_dir_bwd(L.ptr(packed, torch.uint8), L.ptr(ctx["dsave"], torch.uint8),
+                                                 L.ptr(g_do), m, L.ptr(dscratch, torch.uint8), L.ptr(g_full), ld,
+                                                 L.ptr(grad_flat), L.stream()), "refnerf_dir_bwd")
+                g_dir_in = g_full[:, :dir_in.shape[1]]
+            else:
+                ops.dense_bwd_weight(ctx["hcol"], g_do, G[ns + 1][0], G[ns + 1][1])
+                gy = ops.dense_bwd_input(g_do, W[ns + 1][0], gate=ctx["hcol"])
+                ops.dense_bwd_weight(dir_in, gy, G[ns][0], G[ns][1])
+                g_dir_in = ops.dense_bwd_input(gy, W[ns][0], out=g_full[:, :dir_in.shape[1]])
             u = ops.refnerf_head_bwd(dir_in, ctx["nraw"], d, self.sh_degree, g_density.reshape(-1).contiguous(), g_df,
                                      g_sp, g_dir_in[:, hd:], g_aux2, g_dir_in)
         shape = L.NerfShape(5, 4, 256, 128, 10, 4)
