@@ -288,21 +288,44 @@ def main():
 
     comm_abi_check = None
     if world > 1:
-        # exercise the C-ABI RCCL entries (lnrf_comm_*) across the real ranks, outside the timed region: the same
-        # vector reduced through them and through torch.distributed must agree
-        try:
-            from learn_nerf import parallel as _par
+        # Exercise the C-ABI RCCL entries (lnrf_comm_*) across the real ranks, outside the timed region: the same
+        # vector reduced through them and through torch.distributed must agree.  It must never take the benchmark
+        # down: the unique id is agreed on collectively (a failure on rank 0 reaches every rank as None) and the
+        # communicator part runs in a daemon thread that the main thread abandons after 90 s.
+        import threading
 
-            comm = _par.AbiComm.from_process_group()
-            probe = torch.arange(4096, dtype=torch.float32, device=device) * (rank + 1)
-            ref = probe.clone()
-            comm.all_reduce_sum_(probe)
-            dist.all_reduce(ref)
-            torch.cuda.synchronize()
-            comm_abi_check = "ok" if torch.equal(probe, ref) else "MISMATCH vs torch.distributed"
-            comm.destroy()
-        except Exception as exc:
-            comm_abi_check = f"{type(exc).__name__}: {exc}"
+        from learn_nerf import parallel as _par
+
+        uid = None
+        if rank == 0:
+            try:
+                uid = _par.AbiComm.new_unique_id()
+            except Exception:
+                uid = None
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            comm_abi_check = "unavailable: lnrf_comm_get_unique_id failed on rank 0"
+        else:
+            result = {}
+
+            def _probe():
+                try:
+                    torch.cuda.set_device(local_rank)
+                    comm = _par.AbiComm(box[0], rank, world)
+                    probe = torch.arange(4096, dtype=torch.float32, device=device) * (rank + 1)
+                    comm.all_reduce_sum_(probe)
+                    torch.cuda.synchronize()
+                    expect = torch.arange(4096, dtype=torch.float32, device=device) * (world * (world + 1) / 2)
+                    result["msg"] = "ok" if torch.equal(probe, expect) else "MISMATCH vs the expected sum"
+                    comm.destroy()
+                except Exception as exc:
+                    result["msg"] = f"{type(exc).__name__}: {exc}"
+
+            th = threading.Thread(target=_probe, daemon=True)
+            th.start()
+            th.join(timeout=90.0)
+            comm_abi_check = result.get("msg", "timeout after 90 s (abandoned)")
     for i in range(args.warmup):
         step(Key(i, ray_offset=rank * n), batch)
     barrier()
