@@ -10,6 +10,8 @@
 // d loss / d enc feature-major for the hash-grid scatter, and dumps X / dy fragments (about 1 KiB per
 // evaluation) for the shared split-K weight-gradient body.
 // Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / directional encoding.
+#include <stdlib.h>
+
 #include "fused_chain.h"
 
 namespace lnrf {
@@ -68,25 +70,77 @@ __device__ __forceinline__ bf16x8 masked_by(const f32x16& acc, const bf16x8& ref
   return f;
 }
 
-template <int NE, bool BWD>
+// FUSED (backward only): the weight gradients are formed inside this kernel.  The model has 10 K parameters, so a
+// workgroup can keep its share of dW in registers for the whole launch: the workgroups are persistent (one per CU,
+// groups of 8 tiles taken round-robin), and after every backward step the 8 waves put the layer's X and dy fragments
+// into an LDS staging area (the layout the split-K body of fused_chain.h reads: one 32-evaluation step per wave),
+// then every wave accumulates ONE 32x32 tile of that layer's dW over its share of the 8 steps (transposed
+// ds_read_b64_tr_b16 reads) and the tiles leave by fp32 atomics once, at the end of the launch.  This removes the
+// 34 KiB per tile of X / dy dumps (written and read back: 2.3 GB per step at 4096 rays) and the second launch.
+struct NgpWgradProblem {
+  int shape, x_slot0, y_slot0, do_bias, first_block, n_blocks;
+  int out_dim;             // columns of the Flax kernel (= valid dy features)
+  unsigned w_lo, w_hi, b_lo, b_hi;  // float offsets of kernel / bias in the gradient vector (64-bit, split)
+  int rb0, rb1, rb2, rb3;  // per X fragment: first kernel row ...
+  int rv0, rv1, rv2, rv3;  // ... and how many of its 16 features are real (scalars: keeps the struct in SGPRs)
+};
+struct NgpWgradArgs {
+  NgpWgradProblem p[kNgpLayers];
+};
+struct NgpWgradEpi {
+  static __device__ __forceinline__ void cols(const NgpWgradProblem& pb, int ot, int colr, int& out_idx,
+                                              int& out_dim, int64_t& w_off, int64_t& b_off) {
+    const int idx = 32 * ot + colr;
+    out_idx = idx < pb.out_dim ? idx : -1;
+    out_dim = pb.out_dim;
+    w_off = (int64_t)(((uint64_t)pb.w_hi << 32) | pb.w_lo);
+    b_off = (int64_t)(((uint64_t)pb.b_hi << 32) | pb.b_lo);
+  }
+  static __device__ __forceinline__ int row(const NgpWgradProblem& pb, int f, int r16) {
+    const int base = f == 0 ? pb.rb0 : (f == 1 ? pb.rb1 : (f == 2 ? pb.rb2 : pb.rb3));
+    const int nv = f == 0 ? pb.rv0 : (f == 1 ? pb.rv1 : (f == 2 ? pb.rv2 : pb.rv3));
+    return r16 < nv ? base + r16 : -1;
+  }
+};
+constexpr int kNgpStageStep = 8 * kFragBytes;                 // fused mode: staging bytes per wave (<= 8 fragments per layer)
+constexpr int kNgpFusedLds = kNgpLds + kWaves * kNgpStageStep;  // 113 KiB: one persistent workgroup per CU
+
+template <int NE, bool BWD, bool FUSED = false>
 __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     const char* __restrict__ packed, const float* __restrict__ enc_t, const float* __restrict__ d_g, int lf,
     int64_t M, int64_t n_tiles, float* __restrict__ density, float* __restrict__ rgb,
     const float* __restrict__ g_density, const float* __restrict__ g_rgb, char* __restrict__ scratch,
-    float* __restrict__ g_enc_t) {
+    float* __restrict__ g_enc_t, NgpWgradArgs wargs = NgpWgradArgs{}, float* __restrict__ grads = nullptr) {
+  static_assert(!FUSED || BWD, "FUSED is a backward mode");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
-  const int64_t m = tile * kTileCols + c;
-  const bool valid = m < M;
-
   {
     const float* bias_g = reinterpret_cast<const float*>(packed + kNgpPackBiasOff);
     float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
     for (int i = tid; i < kNgpBiasFloats; i += kThreads) bias_l[i] = bias_g[i];
   }
+  // persistent accumulators of the fused mode.  The layers are dealt to the two halves of the workgroup so that a
+  // wave carries at most three dW tiles (five would not fit next to the chain's fragments): waves 0-3 take
+  // Dense_3 (slot 0), Dense_4 (slot 1), Dense_0 (slot 2); waves 4-7 take Dense_2 (slot 0), Dense_1 (slot 1).
+  constexpr int kWSlots = 3;
+  f32x16 wacc[FUSED ? kWSlots : 1];
+  float wbias[FUSED ? kWSlots : 1];
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int i = 0; i < kWSlots; ++i) {
+      wacc[i] = zero_acc();
+      wbias[i] = 0.0f;
+    }
+  }
+  const int64_t n_groups = n_tiles / kWaves;
+  for (int64_t group = blockIdx.x; group < n_groups; group += FUSED ? (int64_t)gridDim.x : n_groups) {
+  const int64_t tile = group * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  if constexpr (FUSED) __syncthreads();  // previous group's LDS reads (ring, staging) are finished
+
   // encoding fragments: k slot (ks, h, j) <-> feature 16 ks + 8 (j >> 2) + 4 h + (j & 3) (row of enc_t)
   bf16x8 ef[NE];
   static_for<NE>([&](auto ks_) {
@@ -113,7 +167,9 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
 
   using Seq = NgpSeq<NE, BWD>;
   Ring<(Seq::count + kStageFrags - 1) / kStageFrags, Seq> ring;
-  ring.stream = packed;
+  const char* wstream = packed;
+  if constexpr (FUSED) asm volatile("" : "+s"(wstream));  // keep the stage addresses out of the group loop's preheader
+  ring.stream = wstream;
   ring.wave = wave;
   ring.lane = lane;
   ring.prologue();
@@ -139,7 +195,39 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
 
   DumpAddr dump{scratch, n_tiles, tile, c, h};
   auto dump_frag = [&](int slot, const bf16x8& f) {
-    if (BWD) stream_store(dump.at(slot), frag_to_bits(f));  // unconditional: tiles are padded to whole workgroups
+    if (BWD && !FUSED) stream_store(dump.at(slot), frag_to_bits(f));  // unconditional: tiles are padded to whole workgroups
+  };
+  // fused mode: stage fragment f (X fragments first, then dy) of this wave's tile; weight-gradient step of layer P
+  char* stage = smem + kNgpLds + wave * kNgpStageStep;
+  auto stage_frag = [&](int f, const bf16x8& v) {
+    *reinterpret_cast<uint4*>(stage + f * kFragBytes + dump_lane_off(f, c, h)) = frag_to_bits(v);
+  };
+  auto wgrad_layer = [&](auto slot_, auto half_, auto nxf_, auto nyf_) {
+    constexpr int SLOT = decltype(slot_)::value, HALF = decltype(half_)::value;
+    constexpr int NXF = decltype(nxf_)::value, NYF = decltype(nyf_)::value;
+    constexpr int NI = NXF / 2, NO = NYF / 2, NT = NI * NO;  // tiles of this layer's dW
+    constexpr int STEPS = 2 * NT;                            // 4 waves = NT tiles x (4 / NT) k-parts of 8 / (4 / NT) steps
+    __syncthreads();                                         // all 8 tiles staged
+    if ((wave >> 2) == HALF) {
+      const int w4 = wave & 3;
+      const int tile_id = w4 % NT, part = w4 / NT;
+      const int it = tile_id / NO, ot = tile_id % NO;
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const char* buf = smem + kNgpLds + (part * STEPS + st) * kNgpStageStep;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bf16x8 bfv = tr_frag(buf + (NXF + 2 * ot) * kFragBytes, lane, 0, q);
+          if (it == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wbias[SLOT] += (float)bfv[j];
+          }
+          const bf16x8 afv = tr_frag(buf + 2 * it * kFragBytes, lane, 0, q);
+          wacc[SLOT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv, bfv, wacc[SLOT], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // staging area free for the next layer
   };
 
   bf16x8 h0[4], o16, c1[4], c2[4];
@@ -229,6 +317,12 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     const float g_logit = h == 0 ? g_dens * dens : 0.0f;
     dump_frag(kNgpDy4, dy4);
     dump_frag(kNgpDy4 + 1, zero_frag());
+    if constexpr (FUSED) {  // Dense_4: X = c2, dy = dy4
+      static_for<4>([&](auto i_) { stage_frag(decltype(i_)::value, c2[decltype(i_)::value]); });
+      stage_frag(4, dy4);
+      stage_frag(5, zero_frag());
+      wgrad_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});  // Dense_4: waves 0-3, slot 1
+    }
 
     bf16x8 dy3[4], dy2[4], dy1, dy0[4];
     // T0: Dense_4^T -> dc2, relu mask of c2
@@ -241,6 +335,13 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
           dump_frag(kNgpDy3 + 2 * o, dy3[2 * o]);
           dump_frag(kNgpDy3 + 2 * o + 1, dy3[2 * o + 1]);
         });
+    if constexpr (FUSED) {  // Dense_3: X = c1, dy = dy3
+      static_for<4>([&](auto i_) {
+        stage_frag(decltype(i_)::value, c1[decltype(i_)::value]);
+        stage_frag(4 + decltype(i_)::value, dy3[decltype(i_)::value]);
+      });
+      wgrad_layer(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});  // Dense_3: waves 0-3, slot 0
+    }
     // T1: Dense_3^T -> dc1, relu mask of c1
     chain_layer<ngp_bwd_base(1, NE), 4, 2>(
         ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy3[decltype(k_)::value]; },
@@ -251,6 +352,14 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
           dump_frag(kNgpDy2 + 2 * o, dy2[2 * o]);
           dump_frag(kNgpDy2 + 2 * o + 1, dy2[2 * o + 1]);
         });
+    if constexpr (FUSED) {  // Dense_2: X = [d_emb, out] (24 + 16 features in 4 fragments), dy = dy2
+      stage_frag(0, de[0]);
+      stage_frag(1, de[1]);
+      stage_frag(2, o16);
+      stage_frag(3, zero_frag());
+      static_for<4>([&](auto i_) { stage_frag(4 + decltype(i_)::value, dy2[decltype(i_)::value]); });
+      wgrad_layer(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});  // Dense_2: waves 4-7, slot 0
+    }
     // T2: Dense_2^T restricted to the rows of `out` (d_emb has no parameters upstream); the density
     // head adds d exp(out_0) to feature 0 (lane h == 0, register 0)
     chain_layer<ngp_bwd_base(2, NE), 4, 1>(
@@ -262,6 +371,12 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
           dump_frag(kNgpDy1, dy1);
           dump_frag(kNgpDy1 + 1, zero_frag());
         });
+    if constexpr (FUSED) {  // Dense_1: X = h0, dy = dy1
+      static_for<4>([&](auto i_) { stage_frag(decltype(i_)::value, h0[decltype(i_)::value]); });
+      stage_frag(4, dy1);
+      stage_frag(5, zero_frag());
+      wgrad_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});  // Dense_1: waves 4-7, slot 1
+    }
     // T3: Dense_1^T -> dh0, relu mask of h0
     chain_layer<ngp_bwd_base(3, NE), 1, 2>(
         ring, [&](auto) { return zero_acc(); }, [&](auto) -> bf16x8 { return dy1; },
@@ -272,6 +387,13 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
           dump_frag(kNgpDy0 + 2 * o, dy0[2 * o]);
           dump_frag(kNgpDy0 + 2 * o + 1, dy0[2 * o + 1]);
         });
+    if constexpr (FUSED) {  // Dense_0: X = hash-grid encoding, dy = dy0
+      stage_frag(0, ef[0]);
+      if constexpr (NE > 1) stage_frag(1, ef[1]);
+      else stage_frag(1, zero_frag());
+      static_for<4>([&](auto i_) { stage_frag(2 + decltype(i_)::value, dy0[decltype(i_)::value]); });
+      wgrad_layer(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});  // Dense_0: waves 0-3, slot 2
+    }
     // T4: Dense_0^T -> d loss / d enc, feature-major fp32 for the hash-grid scatter
     chain_layer<ngp_bwd_base(4, NE), 4, 1>(
         ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy0[decltype(k_)::value]; },
@@ -283,36 +405,46 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
           }
         });
   }
+  }  // group loop
+  if constexpr (FUSED) {
+    // the launch's share of dW: one tile per layer and wave, added once (fp32 atomics)
+    const int colr = lane & 31, hh = lane >> 5;
+    auto flush = [&](auto p_, auto slot_, auto half_, auto nxf_, auto nyf_) {
+      constexpr int P = decltype(p_)::value, SLOT = decltype(slot_)::value, HALF = decltype(half_)::value;
+      constexpr int NXF = decltype(nxf_)::value, NYF = decltype(nyf_)::value;
+      constexpr int NO = NYF / 2, NT = (NXF / 2) * NO;
+      if ((wave >> 2) != HALF) return;
+      const NgpWgradProblem& pb = wargs.p[P];
+      const int tile_id = (wave & 3) % NT;
+      const int it = tile_id / NO, ot = tile_id % NO;
+      int out_idx = -1, out_dim = 1;
+      int64_t w_off = 0, b_off = 0;
+      NgpWgradEpi::cols(pb, ot, colr, out_idx, out_dim, w_off, b_off);
+      if (it == 0) {
+        float sacc = wbias[SLOT];
+        sacc += __shfl_xor(sacc, 32, 64);
+        if (hh == 0 && out_idx >= 0) atomicAdd(grads + b_off + out_idx, sacc);
+      }
+      static_for<16>([&](auto q_) {
+        constexpr int qq = decltype(q_)::value;
+        const int r = (qq & 3) + 8 * (qq >> 2) + 4 * hh;
+        const int f = 2 * it + (r >> 4);
+        const int in_idx = NgpWgradEpi::row(pb, f, r & 15);
+        if (out_idx >= 0 && in_idx >= 0) atomicAdd(grads + w_off + (int64_t)in_idx * out_dim + out_idx, wacc[SLOT][qq]);
+      });
+    };
+    // (problem index of the host table, accumulator slot, workgroup half, X fragments, dy fragments)
+    flush(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});  // Dense_3
+    flush(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});  // Dense_4
+    flush(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});  // Dense_0
+    flush(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});  // Dense_2
+    flush(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});  // Dense_1
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // weight gradients: the shared split-K body with InstantNGP addressing
 // ---------------------------------------------------------------------------------------------
-struct NgpWgradProblem {
-  int shape, x_slot0, y_slot0, do_bias, first_block, n_blocks;
-  int out_dim;             // columns of the Flax kernel (= valid dy features)
-  unsigned w_lo, w_hi, b_lo, b_hi;  // float offsets of kernel / bias in the gradient vector (64-bit, split)
-  int rb0, rb1, rb2, rb3;  // per X fragment: first kernel row ...
-  int rv0, rv1, rv2, rv3;  // ... and how many of its 16 features are real (scalars: keeps the struct in SGPRs)
-};
-struct NgpWgradArgs {
-  NgpWgradProblem p[kNgpLayers];
-};
-struct NgpWgradEpi {
-  static __device__ __forceinline__ void cols(const NgpWgradProblem& pb, int ot, int colr, int& out_idx,
-                                              int& out_dim, int64_t& w_off, int64_t& b_off) {
-    const int idx = 32 * ot + colr;
-    out_idx = idx < pb.out_dim ? idx : -1;
-    out_dim = pb.out_dim;
-    w_off = (int64_t)(((uint64_t)pb.w_hi << 32) | pb.w_lo);
-    b_off = (int64_t)(((uint64_t)pb.b_hi << 32) | pb.b_lo);
-  }
-  static __device__ __forceinline__ int row(const NgpWgradProblem& pb, int f, int r16) {
-    const int base = f == 0 ? pb.rb0 : (f == 1 ? pb.rb1 : (f == 2 ? pb.rb2 : pb.rb3));
-    const int nv = f == 0 ? pb.rv0 : (f == 1 ? pb.rv1 : (f == 2 ? pb.rv2 : pb.rv3));
-    return r16 < nv ? base + r16 : -1;
-  }
-};
 constexpr int kNgpWgSpi = 4;  // steps per barrier: 2 x 4 x 8 KiB = 64 KiB of LDS, two workgroups per CU
 constexpr int kNgpWgradLds = 2 * kNgpWgSpi * 8 * kFragBytes;
 
@@ -467,6 +599,15 @@ extern "C" int lnrf_ngp_mlp_fwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   return LNRF_OK;
 }
 
+// LNRF_NGP_WGRAD=split in the environment selects the older two-launch backward (dumps + split-K kernel)
+static bool ngp_fused_wgrad_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("LNRF_NGP_WGRAD");
+    return !(v && v[0] == 's');
+  }();
+  return on;
+}
+
 extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t,
                                 const float* d, const float* g_density, const float* g_rgb, int64_t m,
                                 void* scratch, float* g_enc_t, float* grads, lnrf_stream_t stream) {
@@ -478,20 +619,7 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   const dim3 grid((unsigned)((n_tiles + kWaves - 1) / kWaves)), block(kThreads);
   hipStream_t st = as_stream(stream);
   int rc;
-  if (desc->enc_dim <= 16) {
-    rc = ngp_ensure_lds(ngp_mlp_kernel<1, true>, kNgpLds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((ngp_mlp_kernel<1, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
-                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
-  } else {
-    rc = ngp_ensure_lds(ngp_mlp_kernel<2, true>, kNgpLds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((ngp_mlp_kernel<2, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
-                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
-  }
-  LNRF_LAUNCH_CHECK();
-
-  // weight gradients: one launch, five Dense problems
+  // weight-gradient problems (five Dense layers)
   const NgpOffsets off = ngp_offsets(desc);
   const int lf = desc->enc_dim;
   NgpWgradArgs a;
@@ -518,6 +646,42 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   add(2, 1, kNgpXH0, kNgpDy1, 1, 0, 16, 16, 16, 32, 16, 48, 16);
   add(3, 1, kNgpXC2, kNgpDy4, 4, 0, 16, 16, 16, 32, 16, 48, 16);
   add(4, 0, kNgpXEnc, kNgpDy0, 0, 0, lf < 16 ? lf : 16, 16, lf > 16 ? lf - 16 : 0, 0, 0, 0, 0);
+  if (ngp_fused_wgrad_enabled()) {
+    // one persistent workgroup per CU forms the weight gradients itself (no dumps, no second launch)
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
+    int64_t nb = n_tiles / kWaves;
+    if (nb > cus) nb = cus;
+    const dim3 pgrid((unsigned)nb);
+    if (desc->enc_dim <= 16) {
+      rc = ngp_ensure_lds(ngp_mlp_kernel<1, true, true>, kNgpFusedLds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((ngp_mlp_kernel<1, true, true>), pgrid, block, kNgpFusedLds, st, (const char*)packed, enc_t, d,
+                         (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t, a, grads);
+    } else {
+      rc = ngp_ensure_lds(ngp_mlp_kernel<2, true, true>, kNgpFusedLds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((ngp_mlp_kernel<2, true, true>), pgrid, block, kNgpFusedLds, st, (const char*)packed, enc_t, d,
+                         (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t, a, grads);
+    }
+    LNRF_LAUNCH_CHECK();
+    return LNRF_OK;
+  }
+  if (desc->enc_dim <= 16) {
+    rc = ngp_ensure_lds(ngp_mlp_kernel<1, true>, kNgpLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_kernel<1, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
+                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
+  } else {
+    rc = ngp_ensure_lds(ngp_mlp_kernel<2, true>, kNgpLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_kernel<2, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
+                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
+  }
+  LNRF_LAUNCH_CHECK();
+
   rc = ngp_ensure_lds(ngp_wgrad_kernel, kNgpWgradLds);
   if (rc) return rc;
   hipLaunchKernelGGL(ngp_wgrad_kernel, dim3((unsigned)first), dim3(kThreads), kNgpWgradLds, st, a,
