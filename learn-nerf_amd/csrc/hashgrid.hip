@@ -288,6 +288,23 @@ struct BucketTuple {
   unsigned rel;  // entry index within the 4K-entry slice
   float v0, v1;
 };
+// Plain scatter (u == nullptr): the trilinear weights are <= 1, so every contribution is bounded by the level's
+// max |d loss / d enc|, which a small pre-pass (level_absmax_kernel) provides BEFORE binning.  The values are then
+// quantised right away to 26-bit fixed point relative to that bound (2^-25 of the level maximum, about fp32's own
+// resolution at the maximum) and a tuple is 8 bytes: {q0 : 26 | rel[0:6], q1 : 26 | rel[6:12]} — a third less tuple
+// traffic than {rel, float, float}, integer sums in the reduce pass without any floating-point conversion.
+struct PackedTuple {
+  unsigned w0, w1;
+};
+constexpr int kQuantBits = 26;
+__device__ __forceinline__ PackedTuple pack_tuple(unsigned rel, float v0, float v1, float scale) {
+  const int q0 = __float2int_rn(v0 * scale), q1 = __float2int_rn(v1 * scale);
+  PackedTuple t;
+  t.w0 = ((unsigned)q0 & 0x03FFFFFFu) | ((rel & 63u) << 26);
+  t.w1 = ((unsigned)q1 & 0x03FFFFFFu) | ((rel >> 6) << 26);
+  return t;
+}
+
 constexpr int kBinChunk = 2048;  // samples per binning workgroup
 constexpr int kBucketEntries = 4096;  // 64 KiB of int64 x 2 features
 constexpr int kMaxSlices = 256;       // table <= 1M entries
@@ -321,6 +338,21 @@ __device__ __forceinline__ unsigned run_reserve(unsigned* counter, unsigned b, b
   return base + (unsigned)(lane - hl);
 }
 
+// max |g| over the two feature rows of every bucketed level: level_max[li] (float bits; zeroed by the caller)
+__global__ void level_absmax_kernel(BucketPlan plan, const float* __restrict__ g_enc_t, int64_t M,
+                                    unsigned* __restrict__ level_max) {
+  const int li = blockIdx.y;
+  const float* __restrict__ g = g_enc_t + (int64_t)(2 * plan.level[li]) * M;  // two consecutive rows of M floats
+  float vmax = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * M; i += (int64_t)gridDim.x * blockDim.x)
+    vmax = fmaxf(vmax, fabsf(g[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[li], __float_as_uint(vmax));
+}
+
+template <bool QUANT>
 __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float* __restrict__ x,
                                     const float* __restrict__ u, int64_t M, const float* __restrict__ g_enc_t,
                                     BucketTuple* __restrict__ tuples, unsigned* __restrict__ cursors,
@@ -332,6 +364,13 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
   const int S = plan.slices[li];
   const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
   BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li];
+  PackedTuple* __restrict__ ptup = reinterpret_cast<PackedTuple*>(tuples) + plan.tuple_off[li];
+  float qscale = 0.0f;  // QUANT: 2^(25 - e) with level max < 2^e (level_absmax_kernel ran before this launch)
+  if (QUANT) {
+    int e = 0;
+    frexpf(__uint_as_float(level_max[li]), &e);
+    qscale = ldexpf(1.0f, kQuantBits - 1 - e);
+  }
   unsigned* __restrict__ cur = cursors + plan.cursor_off[li];
   const long long cap = plan.cap[li];
   for (int i = threadIdx.x; i < S; i += blockDim.x) s_count[i] = 0u;
@@ -390,13 +429,17 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
       const unsigned off = hashed ? (valid ? atomicAdd(&s_count[b], 1u) : 0u) : run_reserve(s_count, b, valid);
       if (valid) {
         const long long pos = (long long)s_base[b] + off;
-        vmax = fmaxf(vmax, fmaxf(fabsf(w * g0), fabsf(w * g1)));
+        if (!QUANT) vmax = fmaxf(vmax, fmaxf(fabsf(w * g0), fabsf(w * g1)));
         if (pos < cap) {
-          BucketTuple t;
-          t.rel = idx - b * kBucketEntries;
-          t.v0 = w * g0;
-          t.v1 = w * g1;
-          tup[(long long)b * cap + pos] = t;
+          if (QUANT) {
+            ptup[(long long)b * cap + pos] = pack_tuple(idx - b * kBucketEntries, w * g0, w * g1, qscale);
+          } else {
+            BucketTuple t;
+            t.rel = idx - b * kBucketEntries;
+            t.v0 = w * g0;
+            t.v1 = w * g1;
+            tup[(long long)b * cap + pos] = t;
+          }
         } else {  // bucket full: rare, stay correct
           float* gt = g_tables + d.table_offset[level] + 2 * (int64_t)idx;
           atomicAdd(gt, w * g0);
@@ -405,10 +448,12 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
       }
     }
   }
-  // level max |value| (fixed-point scale of pass B): non-negative floats order like their bit patterns
+  if (!QUANT) {
+    // level max |value| (fixed-point scale of pass B): non-negative floats order like their bit patterns
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[li], __float_as_uint(vmax));
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[li], __float_as_uint(vmax));
+  }
 }
 
 // Pass B.  A bucket is split among plan.split[level] workgroups (few-slice levels would otherwise leave
@@ -416,6 +461,7 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
 // The tuple stream is read kReduceUnroll tuples per thread ahead of the LDS atomics that consume it.
 constexpr int kReduceThreads = 512;
 constexpr int kReduceUnroll = 4;
+template <bool QUANT>
 __global__ __launch_bounds__(kReduceThreads) void hashgrid_reduce_kernel(
     HashGridDesc d, BucketPlan plan, const BucketTuple* __restrict__ tuples, const unsigned* __restrict__ cursors,
     const unsigned* __restrict__ level_max, float* __restrict__ g_tables) {
@@ -440,8 +486,32 @@ __global__ __launch_bounds__(kReduceThreads) void hashgrid_reduce_kernel(
   frexpf(__uint_as_float(level_max[li]), &e);
   const int lg = 64 - __clzll((hi - lo) | 1ll);
   const int fixed_bits = 62 - lg;  // 46 for a 64K-tuple bucket
-  const double scale = ldexp(1.0, fixed_bits - e), inv_scale = ldexp(1.0, e - fixed_bits);
+  const double scale = ldexp(1.0, fixed_bits - e);
+  const double inv_scale = QUANT ? ldexp(1.0, e - (kQuantBits - 1)) : ldexp(1.0, e - fixed_bits);
   const BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li] + (long long)b * plan.cap[li];
+  if (QUANT) {
+    // 8-byte tuples: 26-bit values (sign-extended) summed as they are — 2^38 of them fit a signed 64-bit sum
+    const uint2* __restrict__ pt = reinterpret_cast<const uint2*>(reinterpret_cast<const PackedTuple*>(tuples) +
+                                                                  plan.tuple_off[li] + (long long)b * plan.cap[li]);
+    for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += (long long)kReduceUnroll * kReduceThreads) {
+      uint2 t[kReduceUnroll];
+      bool ok[kReduceUnroll];
+#pragma unroll
+      for (int q = 0; q < kReduceUnroll; ++q) {
+        const long long i = i0 + (long long)q * kReduceThreads;
+        ok[q] = i < hi;
+        t[q] = pt[ok[q] ? i : hi - 1];
+      }
+#pragma unroll
+      for (int q = 0; q < kReduceUnroll; ++q) {
+        const unsigned rel = (t[q].x >> 26) | ((t[q].y >> 26) << 6);
+        const long long q0 = ok[q] ? (long long)(((int)(t[q].x << 6)) >> 6) : 0ll;
+        const long long q1 = ok[q] ? (long long)(((int)(t[q].y << 6)) >> 6) : 0ll;
+        atomicAdd(&lds_q[2 * rel], (unsigned long long)q0);
+        atomicAdd(&lds_q[2 * rel + 1], (unsigned long long)q1);
+      }
+    }
+  } else
   for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += (long long)kReduceUnroll * kReduceThreads) {
     BucketTuple t[kReduceUnroll];
     // branch-free: out-of-range slots re-read the last tuple and add zeros (a guarded load makes the
@@ -647,11 +717,24 @@ extern "C" int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const 
     hipError_t e = hipMemsetAsync(cursors, 0, (size_t)cursor_bytes, as_stream(stream));
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(bucket cursors)");
     const unsigned chunks = (unsigned)((m + kBinChunk - 1) / kBinChunk);
-    hipLaunchKernelGGL(hashgrid_bin_kernel, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d, plan, x,
-                       u, m, g_enc_t, tuples, cursors, level_max, g_tables);
-    LNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hashgrid_reduce_kernel, dim3((unsigned)plan.wg_off[plan.n]), dim3(kReduceThreads), 64 * 1024,
-                       as_stream(stream), d, plan, tuples, cursors, level_max, g_tables);
+    if (u == nullptr) {
+      // weights <= 1: quantised 8-byte tuples against the level's max |g| (found first)
+      hipLaunchKernelGGL(level_absmax_kernel, dim3(256, (unsigned)plan.n), dim3(256), 0, as_stream(stream), plan, g_enc_t,
+                         m, level_max);
+      LNRF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(hashgrid_bin_kernel<true>, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d,
+                         plan, x, u, m, g_enc_t, tuples, cursors, level_max, g_tables);
+      LNRF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(hashgrid_reduce_kernel<true>, dim3((unsigned)plan.wg_off[plan.n]), dim3(kReduceThreads),
+                         64 * 1024, as_stream(stream), d, plan, tuples, cursors, level_max, g_tables);
+    } else {
+      // directional-derivative weights are unbounded: fp32 tuples, level maximum found while binning
+      hipLaunchKernelGGL(hashgrid_bin_kernel<false>, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d,
+                         plan, x, u, m, g_enc_t, tuples, cursors, level_max, g_tables);
+      LNRF_LAUNCH_CHECK();
+      hipLaunchKernelGGL(hashgrid_reduce_kernel<false>, dim3((unsigned)plan.wg_off[plan.n]), dim3(kReduceThreads),
+                         64 * 1024, as_stream(stream), d, plan, tuples, cursors, level_max, g_tables);
+    }
     LNRF_LAUNCH_CHECK();
   }
   // levels with 8K < entries <= 512K go to the sliced LDS kernel, the rest to the direct kernel
