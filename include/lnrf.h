@@ -217,11 +217,14 @@ int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m,
 /* Same scatter with caller-provided scratch (lnrf_hashgrid_bwd_scratch_bytes): hashed levels are reduced
  * without global float atomics (bin by 8K-entry table slice, then one workgroup per bucket accumulates in
  * LDS).  u == NULL: value weights (first-order gradient); u [M,3]: derivative weights (see bwd_dir).
+ * level_absmax (optional, u == NULL only): n_levels floats, level_absmax[l] >= max |g_enc_t rows 2l, 2l+1| — the
+ * scale of the pass's fixed-point tuples; lnrf_ngp_mlp_bwd produces it while writing g_enc_t.  NULL: found by a
+ * pass over g_enc_t.  A bound that is too small wraps the fixed-point values (caller error).
  * scratch == NULL falls back to the LDS-sliced / atomic kernels. */
 int64_t lnrf_hashgrid_bwd_scratch_bytes(const lnrf_hashgrid_desc* desc, int64_t m);
 int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
-                               const float* g_enc_t, float* g_tables, void* scratch, int64_t scratch_bytes,
-                               lnrf_stream_t stream);
+                               const float* g_enc_t, const float* level_absmax, float* g_tables, void* scratch,
+                               int64_t scratch_bytes, lnrf_stream_t stream);
 
 /* Input-derivative maps of the encoding, needed when a Ref-NeRF head sits on the hash grid
  * (InstantNGPRefNERFModel, instant_ngp.py:57-89: normals = -d out[:,0]/dx, ref_nerf.py:38-43):
@@ -441,10 +444,12 @@ int lnrf_ngp_mlp_fwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const fl
                      int64_t m, float* density, float* rgb, lnrf_stream_t stream);
 /* VJP of lnrf_ngp_mlp_fwd (recomputes the forward): g_enc_t [enc_dim][m] = d loss / d enc (written),
  * grads (the flat gradient vector, same layout as params) += Dense kernel / bias gradients.
+ * level_absmax (optional): enc_dim / 2 floats ZEROED by the caller; on return level_absmax[l] = max |g_enc_t| over
+ * the two feature rows of level l (max-combined with what was there), for lnrf_hashgrid_bwd_bucketed.
  * scratch: lnrf_ngp_mlp_scratch_bytes(desc, m) bytes. */
 int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t, const float* d,
                      const float* g_density, const float* g_rgb, int64_t m, void* scratch, float* g_enc_t,
-                     float* grads, lnrf_stream_t stream);
+                     float* level_absmax, float* grads, lnrf_stream_t stream);
 
 /* optax.adam (train.py:59), fused over a flat buffer:
  *   g' = g*grad_scale; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;

@@ -338,7 +338,7 @@ __device__ __forceinline__ unsigned run_reserve(unsigned* counter, unsigned b, b
   return base + (unsigned)(lane - hl);
 }
 
-// max |g| over the two feature rows of every bucketed level: level_max[li] (float bits; zeroed by the caller)
+// max |g| over the two feature rows of every bucketed level: level_max[level] (float bits; zeroed by the caller)
 __global__ void level_absmax_kernel(BucketPlan plan, const float* __restrict__ g_enc_t, int64_t M,
                                     unsigned* __restrict__ level_max) {
   const int li = blockIdx.y;
@@ -349,7 +349,7 @@ __global__ void level_absmax_kernel(BucketPlan plan, const float* __restrict__ g
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
   // non-negative floats order like their bit patterns
-  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[li], __float_as_uint(vmax));
+  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[plan.level[li]], __float_as_uint(vmax));
 }
 
 template <bool QUANT>
@@ -368,7 +368,7 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
   float qscale = 0.0f;  // QUANT: 2^(25 - e) with level max < 2^e (level_absmax_kernel ran before this launch)
   if (QUANT) {
     int e = 0;
-    frexpf(__uint_as_float(level_max[li]), &e);
+    frexpf(__uint_as_float(level_max[plan.level[li]]), &e);
     qscale = ldexpf(1.0f, kQuantBits - 1 - e);
   }
   unsigned* __restrict__ cur = cursors + plan.cursor_off[li];
@@ -452,7 +452,7 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
     // level max |value| (fixed-point scale of pass B): non-negative floats order like their bit patterns
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[li], __float_as_uint(vmax));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[plan.level[li]], __float_as_uint(vmax));
   }
 }
 
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kReduceThreads) void hashgrid_reduce_kernel(
   // power-of-two scale: level max < 2^e and at most n = hi - lo < 2^lg terms per entry, so values scaled by
   // 2^(62 - lg - e) cannot overflow the signed 64-bit sum whatever the sample distribution is
   int e = 0;
-  frexpf(__uint_as_float(level_max[li]), &e);
+  frexpf(__uint_as_float(level_max[plan.level[li]]), &e);
   const int lg = 64 - __clzll((hi - lo) | 1ll);
   const int fixed_bits = 62 - lg;  // 46 for a 64K-tuple bucket
   const double scale = ldexp(1.0, fixed_bits - e);
@@ -691,12 +691,12 @@ extern "C" int64_t lnrf_hashgrid_bwd_scratch_bytes(const lnrf_hashgrid_desc* des
 
 extern "C" int lnrf_hashgrid_bwd_dir(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
                                      const float* g_enc_t, float* g_tables, lnrf_stream_t stream) {
-  return lnrf_hashgrid_bwd_bucketed(desc, x, u, m, g_enc_t, g_tables, nullptr, 0, stream);
+  return lnrf_hashgrid_bwd_bucketed(desc, x, u, m, g_enc_t, nullptr, g_tables, nullptr, 0, stream);
 }
 
 extern "C" int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
-                                          const float* g_enc_t, float* g_tables, void* scratch,
-                                          int64_t scratch_bytes, lnrf_stream_t stream) {
+                                          const float* g_enc_t, const float* level_absmax, float* g_tables,
+                                          void* scratch, int64_t scratch_bytes, lnrf_stream_t stream) {
   int rc = check_desc(desc);
   if (rc) return rc;
   LNRF_CHECK_ARG(x && g_enc_t && g_tables, "null pointer");
@@ -718,10 +718,15 @@ extern "C" int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const 
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(bucket cursors)");
     const unsigned chunks = (unsigned)((m + kBinChunk - 1) / kBinChunk);
     if (u == nullptr) {
-      // weights <= 1: quantised 8-byte tuples against the level's max |g| (found first)
-      hipLaunchKernelGGL(level_absmax_kernel, dim3(256, (unsigned)plan.n), dim3(256), 0, as_stream(stream), plan, g_enc_t,
-                         m, level_max);
-      LNRF_LAUNCH_CHECK();
+      // weights <= 1: quantised 8-byte tuples against the level's max |g| — handed in by the producer of g_enc_t
+      // (lnrf_ngp_mlp_bwd finds it while it writes the rows) or found first by a pass of its own
+      if (level_absmax) {
+        level_max = reinterpret_cast<unsigned*>(const_cast<float*>(level_absmax));  // read only from here on
+      } else {
+        hipLaunchKernelGGL(level_absmax_kernel, dim3(256, (unsigned)plan.n), dim3(256), 0, as_stream(stream), plan,
+                           g_enc_t, m, level_max);
+        LNRF_LAUNCH_CHECK();
+      }
       hipLaunchKernelGGL(hashgrid_bin_kernel<true>, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d,
                          plan, x, u, m, g_enc_t, tuples, cursors, level_max, g_tables);
       LNRF_LAUNCH_CHECK();

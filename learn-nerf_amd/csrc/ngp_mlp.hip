@@ -103,15 +103,33 @@ struct NgpWgradEpi {
   }
 };
 constexpr int kNgpStageStep = 8 * kFragBytes;                 // fused mode: staging bytes per wave (<= 8 fragments per layer)
-constexpr int kNgpFusedLds = kNgpLds + kWaves * kNgpStageStep;  // 113 KiB: one persistent workgroup per CU
+constexpr int kNgpGmaxOff = kNgpLds + kWaves * kNgpStageStep;    // fused mode: 8 running maxima per lane (32 B)
+constexpr int kNgpFusedLds = kNgpGmaxOff + kThreads * 32;        // 129 KiB: one persistent workgroup per CU
 
 template <int NE, bool BWD, bool FUSED = false>
 __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     const char* __restrict__ packed, const float* __restrict__ enc_t, const float* __restrict__ d_g, int lf,
     int64_t M, int64_t n_tiles, float* __restrict__ density, float* __restrict__ rgb,
     const float* __restrict__ g_density, const float* __restrict__ g_rgb, char* __restrict__ scratch,
-    float* __restrict__ g_enc_t, NgpWgradArgs wargs = NgpWgradArgs{}, float* __restrict__ grads = nullptr) {
+    float* __restrict__ g_enc_t, float* __restrict__ lmax_parts = nullptr, NgpWgradArgs wargs = NgpWgradArgs{},
+    float* __restrict__ grads = nullptr) {
   static_assert(!FUSED || BWD, "FUSED is a backward mode");
+  // backward: running max |d loss / d enc| of the rows this lane writes, 8 slots (rows 4h + 8j + {0,1} / + {2,3} are
+  // the two features of levels 2h + 4j / 2h + 4j + 1): the fixed-point scale of the scatter pass.  The persistent
+  // (FUSED) kernel keeps the slots in LDS (32 bytes per lane, its registers are full), reduces them once at the end
+  // and stores one row of 16 per workgroup — plain stores; ngp_level_max_kernel folds the rows.  (Same-address
+  // global atomics retire at ~10 ns each: 256 workgroups x 16 of them at the end of the launch measured +30 us,
+  // a wave reduction per group +35 us.)
+  __shared__ unsigned s_lmax[16];
+  float gmax[(BWD && !FUSED) ? 8 : 1];
+  if constexpr (BWD && !FUSED) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gmax[i] = 0.0f;
+  }
+  if constexpr (FUSED) {
+    float4* gm = reinterpret_cast<float4*>(smem + kNgpGmaxOff + threadIdx.x * 32);
+    gm[0] = gm[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,6 +138,7 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     const float* bias_g = reinterpret_cast<const float*>(packed + kNgpPackBiasOff);
     float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
     for (int i = tid; i < kNgpBiasFloats; i += kThreads) bias_l[i] = bias_g[i];
+    if (tid < 16) s_lmax[tid] = 0u;
   }
   // persistent accumulators of the fused mode.  The layers are dealt to the two halves of the workgroup so that a
   // wave carries at most three dW tiles (five would not fit next to the chain's fragments): waves 0-3 take
@@ -398,14 +417,45 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     chain_layer<ngp_bwd_base(4, NE), 4, 1>(
         ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return dy0[decltype(k_)::value]; },
         [&](auto, const f32x16& acc) {
+          float tmax[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) tmax[i] = 0.0f;
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (valid && row < lf) g_enc_t[(int64_t)row * M + m] = acc[q];
+            if (valid && row < lf) {
+              g_enc_t[(int64_t)row * M + m] = acc[q];
+              tmax[q >> 1] = fmaxf(tmax[q >> 1], fabsf(acc[q]));
+            }
+          }
+          if constexpr (FUSED) {
+            float4* gm = reinterpret_cast<float4*>(smem + kNgpGmaxOff + tid * 32);
+            const float4 a = gm[0], b = gm[1];
+            gm[0] = make_float4(fmaxf(a.x, tmax[0]), fmaxf(a.y, tmax[1]), fmaxf(a.z, tmax[2]), fmaxf(a.w, tmax[3]));
+            gm[1] = make_float4(fmaxf(b.x, tmax[4]), fmaxf(b.y, tmax[5]), fmaxf(b.z, tmax[6]), fmaxf(b.w, tmax[7]));
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gmax[i] = fmaxf(gmax[i], tmax[i]);
           }
         });
   }
   }  // group loop
+  if constexpr (BWD) {
+    if (lmax_parts) {  // kernel argument: uniform
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v;
+        if constexpr (FUSED) v = reinterpret_cast<const float*>(smem + kNgpGmaxOff + tid * 32)[i];
+        else v = gmax[i];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        // non-negative floats order like their bit patterns
+        if (c == 0 && v > 0.0f) atomicMax(&s_lmax[4 * (i >> 1) + 2 * h + (i & 1)], __float_as_uint(v));
+      }
+      __syncthreads();
+      if (tid < 16) lmax_parts[(int64_t)blockIdx.x * 16 + tid] = __uint_as_float(s_lmax[tid]);
+    }
+  }
   if constexpr (FUSED) {
     // the launch's share of dW: one tile per layer and wave, added once (fp32 atomics)
     const int colr = lane & 31, hh = lane >> 5;
@@ -440,6 +490,21 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     flush(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});  // Dense_2
     flush(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});  // Dense_1
   }
+}
+
+// level_absmax[l] = max(level_absmax[l], max over the workgroup rows parts[n_parts][16]); one workgroup of 256 threads
+__global__ __launch_bounds__(256) void ngp_level_max_kernel(const float* __restrict__ parts, int n_parts, int n_levels,
+                                                            unsigned* __restrict__ level_absmax) {
+  __shared__ unsigned s_max[16];
+  if (threadIdx.x < 16) s_max[threadIdx.x] = 0u;
+  __syncthreads();
+  const int l = threadIdx.x & 15;
+  float v = 0.0f;
+  for (int p = threadIdx.x >> 4; p < n_parts; p += 16) v = fmaxf(v, parts[(int64_t)p * 16 + l]);
+  if (v > 0.0f) atomicMax(&s_max[l], __float_as_uint(v));
+  __syncthreads();
+  if ((int)threadIdx.x < n_levels && threadIdx.x < 16 && s_max[threadIdx.x] != 0u)
+    atomicMax(&level_absmax[threadIdx.x], s_max[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -558,8 +623,11 @@ static int ngp_ensure_lds(K kernel, int bytes) {
 extern "C" int64_t lnrf_ngp_mlp_packed_bytes(const lnrf_ngp_mlp_desc* desc) {
   return ngp_supported(desc) ? kNgpPackBytes : -1;
 }
+static int64_t ngp_lmax_bytes(int64_t n_tiles) { return (n_tiles + kWaves - 1) / kWaves * 16 * (int64_t)sizeof(float); }
+
 extern "C" int64_t lnrf_ngp_mlp_scratch_bytes(const lnrf_ngp_mlp_desc* desc, int64_t m) {
-  return ngp_supported(desc) ? (int64_t)kNgpSlots * ngp_tiles(m) * kFragBytes : -1;
+  // fragment dumps of the two-launch path + one row of 16 per-level maxima per workgroup (either path)
+  return ngp_supported(desc) ? (int64_t)kNgpSlots * ngp_tiles(m) * kFragBytes + ngp_lmax_bytes(ngp_tiles(m)) : -1;
 }
 
 extern "C" int lnrf_ngp_mlp_pack(const lnrf_ngp_mlp_desc* desc, const float* params, void* packed,
@@ -610,7 +678,8 @@ static bool ngp_fused_wgrad_enabled() {
 
 extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t,
                                 const float* d, const float* g_density, const float* g_rgb, int64_t m,
-                                void* scratch, float* g_enc_t, float* grads, lnrf_stream_t stream) {
+                                void* scratch, float* g_enc_t, float* level_absmax, float* grads,
+                                lnrf_stream_t stream) {
   NGP_REQUIRE_SUPPORTED("lnrf_ngp_mlp_bwd");
   LNRF_CHECK_ARG(m >= 0, "bad m");
   if (m == 0) return LNRF_OK;
@@ -619,6 +688,11 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   const dim3 grid((unsigned)((n_tiles + kWaves - 1) / kWaves)), block(kThreads);
   hipStream_t st = as_stream(stream);
   int rc;
+  // per-workgroup rows of level maxima live behind the dumps in the scratch buffer
+  float* lmax_parts = level_absmax ? reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) +
+                                                              (int64_t)kNgpSlots * n_tiles * kFragBytes)
+                                   : nullptr;
+  const int n_levels = desc->enc_dim / 2;
   // weight-gradient problems (five Dense layers)
   const NgpOffsets off = ngp_offsets(desc);
   const int lf = desc->enc_dim;
@@ -659,28 +733,42 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
       rc = ngp_ensure_lds(ngp_mlp_kernel<1, true, true>, kNgpFusedLds);
       if (rc) return rc;
       hipLaunchKernelGGL((ngp_mlp_kernel<1, true, true>), pgrid, block, kNgpFusedLds, st, (const char*)packed, enc_t, d,
-                         (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t, a, grads);
+                         (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t,
+                         lmax_parts, a, grads);
     } else {
       rc = ngp_ensure_lds(ngp_mlp_kernel<2, true, true>, kNgpFusedLds);
       if (rc) return rc;
       hipLaunchKernelGGL((ngp_mlp_kernel<2, true, true>), pgrid, block, kNgpFusedLds, st, (const char*)packed, enc_t, d,
-                         (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t, a, grads);
+                         (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t,
+                         lmax_parts, a, grads);
     }
     LNRF_LAUNCH_CHECK();
+    if (lmax_parts) {
+      hipLaunchKernelGGL(ngp_level_max_kernel, dim3(1), dim3(256), 0, st, lmax_parts, (int)nb, n_levels,
+                         reinterpret_cast<unsigned*>(level_absmax));
+      LNRF_LAUNCH_CHECK();
+    }
     return LNRF_OK;
   }
   if (desc->enc_dim <= 16) {
     rc = ngp_ensure_lds(ngp_mlp_kernel<1, true>, kNgpLds);
     if (rc) return rc;
     hipLaunchKernelGGL((ngp_mlp_kernel<1, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
-                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
+                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t,
+                       lmax_parts);
   } else {
     rc = ngp_ensure_lds(ngp_mlp_kernel<2, true>, kNgpLds);
     if (rc) return rc;
     hipLaunchKernelGGL((ngp_mlp_kernel<2, true>), grid, block, kNgpLds, st, (const char*)packed, enc_t, d,
-                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t);
+                       (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, (char*)scratch, g_enc_t,
+                       lmax_parts);
   }
   LNRF_LAUNCH_CHECK();
+  if (lmax_parts) {
+    hipLaunchKernelGGL(ngp_level_max_kernel, dim3(1), dim3(256), 0, st, lmax_parts, (int)grid.x, n_levels,
+                       reinterpret_cast<unsigned*>(level_absmax));
+    LNRF_LAUNCH_CHECK();
+  }
 
   rc = ngp_ensure_lds(ngp_wgrad_kernel, kNgpWgradLds);
   if (rc) return rc;

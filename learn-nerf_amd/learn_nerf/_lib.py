@@ -65,7 +65,7 @@ PROTOTYPES = {
     "lnrf_hashgrid_fwd": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P]),
     "lnrf_hashgrid_bwd": (c_int32, [POINTER(HashGridDesc), _P, c_int64, _P, _P, _P]),
     "lnrf_hashgrid_bwd_scratch_bytes": (c_int64, [POINTER(HashGridDesc), c_int64]),
-    "lnrf_hashgrid_bwd_bucketed": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "lnrf_hashgrid_bwd_bucketed": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P]),
     "lnrf_hashgrid_jvp": (c_int32, [POINTER(HashGridDesc), _P, _P, _P, c_int64, _P, _P]),
     "lnrf_hashgrid_input_grad": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P]),
     "lnrf_hashgrid_bwd_dir": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P, _P]),
@@ -109,7 +109,7 @@ PROTOTYPES = {
     "lnrf_ngp_mlp_scratch_bytes": (c_int64, [POINTER(NgpMlpDesc), c_int64]),
     "lnrf_ngp_mlp_pack": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P]),
     "lnrf_ngp_mlp_fwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, c_int64, _P, _P, _P]),
-    "lnrf_ngp_mlp_bwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "lnrf_ngp_mlp_bwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "lnrf_dense_bwd_input_gated": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, c_int32,
                                              c_int64, c_int32, c_int32, _P]),
     "lnrf_dense_fwd_gated": (c_int32, [_P, c_int64, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_int64, c_int64,

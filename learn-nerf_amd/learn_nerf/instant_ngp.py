@@ -93,6 +93,10 @@ class HashTableEncoding(MultiresHashTableEncoding):
 class InstantNGPModel(ModelBase):
     """A NeRF model that utilizes a multilevel hash table (instant_ngp.py:16-54)."""
 
+    # TrainLoop: keep the coarse backward on the main stream — this model's gather / scatter / persistent MLP kernels
+    # all contend for the same L2 and LDS, running two of them side by side measured slightly slower
+    overlap_backward_hint = False
+
     table_sizes: Sequence[int] = None
     grid_sizes: Sequence[int] = None
     bbox_min: Sequence[float] = None
@@ -181,14 +185,15 @@ class InstantNGPModel(ModelBase):
             nbytes = L.lib().lnrf_ngp_mlp_scratch_bytes(ctypes.byref(desc), m)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             g_enc_t = torch.empty((lf, m), dtype=F32, device=dev)
+            level_absmax = torch.zeros(lf // 2, dtype=F32, device=dev)  # the scatter's fixed-point scale per level
             gd = g_density.reshape(-1).contiguous()
             gr = g_rgb.reshape(-1, 3).contiguous()
             L.check(L.lib().lnrf_ngp_mlp_bwd(
                 ctypes.byref(desc), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["enc_t"]), L.ptr(ctx["d"]),
-                L.ptr(gd), L.ptr(gr), m, L.ptr(scratch, torch.uint8), L.ptr(g_enc_t), L.ptr(grad_flat),
-                L.stream()), "ngp_mlp_bwd")
+                L.ptr(gd), L.ptr(gr), m, L.ptr(scratch, torch.uint8), L.ptr(g_enc_t), L.ptr(level_absmax),
+                L.ptr(grad_flat), L.stream()), "ngp_mlp_bwd")
         with _prof.section(f"{self.tag}_hashgrid_bwd"):
-            ops.hashgrid_bwd(enc.desc(), ctx["x"], g_enc_t, g_tables)
+            ops.hashgrid_bwd(enc.desc(), ctx["x"], g_enc_t, g_tables, level_absmax=level_absmax)
 
     def dense_dims(self) -> List[Tuple[int, int]]:
         dims, fan = [], len(self.grid_sizes) * self.table_feature_dim

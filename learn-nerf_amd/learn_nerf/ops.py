@@ -317,15 +317,19 @@ def hashgrid_bwd_dir(desc, x: torch.Tensor, u: torch.Tensor, g_enc_t: torch.Tens
     hashgrid_bwd(desc, x, g_enc_t, g_tables, u=u)
 
 
-def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor, u=None):
-    """g_tables += scatter(g_enc_t); hashed levels go through the bucketed (atomic-free) path."""
+def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.Tensor, u=None, level_absmax=None):
+    """g_tables += scatter(g_enc_t); hashed levels go through the bucketed (atomic-free) path.  level_absmax
+    (u is None only): per-level upper bound of |g_enc_t| from the kernel that wrote it (lnrf_ngp_mlp_bwd)."""
     import ctypes
 
     m = x.shape[0]
     nbytes = L.lib().lnrf_hashgrid_bwd_scratch_bytes(ctypes.byref(desc), m)
     scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=_dev(x))
+    if level_absmax is not None and (u is not None or level_absmax.numel() < desc.n_levels):
+        raise ValueError("level_absmax: one float per level, plain scatter only")
     L.check(L.lib().lnrf_hashgrid_bwd_bucketed(ctypes.byref(desc), L.ptr(x), L.ptr(u), m, L.ptr(g_enc_t),
-                                               L.ptr(g_tables), L.ptr(scratch, torch.uint8), int(nbytes), L.stream()),
+                                               L.ptr(level_absmax), L.ptr(g_tables), L.ptr(scratch, torch.uint8),
+                                               int(nbytes), L.stream()),
             "hashgrid_bwd_bucketed")
 
 

@@ -151,6 +151,52 @@ def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m):
     assert ((grad.cpu() - 2 * got).norm() / got.norm()).item() < 1e-3
 
 
+@pytest.mark.parametrize("levels,m", [(6, 2500), (16, 4133), (3, 31)])
+@pytest.mark.parametrize("wgrad", ["fused", "split"])
+def test_ngp_mlp_bwd_level_absmax(levels, m, wgrad, monkeypatch):
+    """
+    lnrf_ngp_mlp_bwd's level_absmax output is exactly max |g_enc_t| over each level's two rows (a max has no rounding),
+    and the scatter fed with it equals the scatter that finds the bound itself (same fixed-point scale).
+    """
+    import ctypes
+    import subprocess
+    import sys
+
+    from learn_nerf import _lib as L
+    from learn_nerf import ops
+
+    if wgrad == "split":
+        # the kernel choice is read once per process: check the other launch mode in a child
+        code = ("import os, sys; os.environ['LNRF_NGP_WGRAD'] = 'split'; sys.path.insert(0, 'tests'); "
+                "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', "
+                f"'tests/test_gpu_instant_ngp.py::test_ngp_mlp_bwd_level_absmax[fused-{levels}-{m}]']))")
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return
+    model, params, flat = make_model(levels, 2 ** 12, precision="bf16")
+    x, d, gen = points(m, seed=levels)
+    _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+    desc = model._mlp_desc()
+    lf = desc.enc_dim
+    scratch = torch.empty(L.lib().lnrf_ngp_mlp_scratch_bytes(ctypes.byref(desc), m), dtype=torch.uint8, device="cuda")
+    g_enc_t = torch.empty((lf, m), device="cuda")
+    lmax = torch.zeros(lf // 2, device="cuda")
+    grad = torch.zeros_like(flat)
+    g_d = torch.randn(m, generator=gen).float().cuda()
+    g_c = torch.randn(m, 3, generator=gen).float().cuda()
+    L.check(L.lib().lnrf_ngp_mlp_bwd(ctypes.byref(desc), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["enc_t"]),
+                                     L.ptr(ctx["d"]), L.ptr(g_d), L.ptr(g_c), m, L.ptr(scratch, torch.uint8),
+                                     L.ptr(g_enc_t), L.ptr(lmax), L.ptr(grad), L.stream()), "ngp_mlp_bwd")
+    want = g_enc_t.abs().reshape(lf // 2, 2 * m).max(dim=1).values
+    assert torch.equal(lmax, want), (lmax, want)
+    enc = model.encoding()
+    a = torch.zeros(enc.num_table_floats(), device="cuda")
+    b = torch.zeros_like(a)
+    ops.hashgrid_bwd(enc.desc(), ctx["x"], g_enc_t, a, level_absmax=lmax)
+    ops.hashgrid_bwd(enc.desc(), ctx["x"], g_enc_t, b)
+    assert torch.equal(a, b) or (a - b).abs().max().item() <= 1e-6 * b.abs().max().item()
+
+
 def test_ngp_fused_unsupported_shape_uses_dense_path():
     """hidden_dim 32 has no fused kernel: precision="bf16" then means bf16 operands on the generic dense path."""
     from oracle.model import bf16_round
@@ -297,7 +343,7 @@ def test_bucketed_scatter_matches_direct_path(clustered):
         b = torch.zeros_like(a)
         ops.hashgrid_bwd(desc, x.cuda(), g, a, u=uu)  # bucketed for all but the 16^3 level
         L.check(L.lib().lnrf_hashgrid_bwd_bucketed(ctypes.byref(desc), L.ptr(x.cuda()), L.ptr(uu), m, L.ptr(g),
-                                                   L.ptr(b), None, 0, L.stream()))  # no scratch: direct kernels
+                                                   None, L.ptr(b), None, 0, L.stream()))  # no scratch: direct kernels
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() < 1e-5 * scale
         assert a.abs().sum().item() > 0
