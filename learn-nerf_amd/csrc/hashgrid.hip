@@ -76,6 +76,37 @@ __device__ __forceinline__ unsigned entry_index(unsigned cx, unsigned cy, unsign
   return cx + (unsigned)G * (cy + (unsigned)G * cz);                            // :199-201
 }
 
+// one sample of one level: 8 corners x 2 features (u != nullptr: directional derivative weights)
+__device__ __forceinline__ void gather_sample(const HashGridDesc& d, int level, int G, int T, int hashed,
+                                              const float2* __restrict__ tab, const float* __restrict__ x,
+                                              const float* __restrict__ u, int64_t M, float* __restrict__ enc_t,
+                                              int64_t m) {
+  const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+  const Corner k = locate(p, d, G);
+  float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+  for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+    for (int yo = 0; yo < 2; ++yo)
+#pragma unroll
+      for (int zo = 0; zo < 2; ++zo) {  // instant_ngp.py:160-175: weight = prod(o ? c : 1 - c)
+        float w;
+        if (u) {
+          float gw[3];
+          corner_weight_grad(k, xo, yo, zo, gw);
+          w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
+        } else {
+          w = corner_weight(k, xo, yo, zo);
+        }
+        const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
+        const float2 v = tab[idx];
+        acc.x += w * v.x;
+        acc.y += w * v.y;
+      }
+  enc_t[(int64_t)(2 * level) * M + m] = acc.x;
+  enc_t[(int64_t)(2 * level + 1) * M + m] = acc.y;
+}
+
 struct LevelList {
   int n;
   int level[kMaxLevels];
@@ -102,32 +133,40 @@ __global__ void hashgrid_fwd_kernel(HashGridDesc d, LevelList ll, const float* _
     __syncthreads();
     tab = lt;  // generic pointer into LDS: the gathers below become ds_read_b64
   }
-  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
-    const float p[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
-    const Corner k = locate(p, d, G);
-    float2 acc = make_float2(0.0f, 0.0f);
-#pragma unroll
-    for (int xo = 0; xo < 2; ++xo)
-#pragma unroll
-      for (int yo = 0; yo < 2; ++yo)
-#pragma unroll
-        for (int zo = 0; zo < 2; ++zo) {  // instant_ngp.py:160-175: weight = prod(o ? c : 1 - c)
-          float w;
-          if (u) {
-            float gw[3];
-            corner_weight_grad(k, xo, yo, zo, gw);
-            w = gw[0] * u[m * 3] + gw[1] * u[m * 3 + 1] + gw[2] * u[m * 3 + 2];
-          } else {
-            w = corner_weight(k, xo, yo, zo);
-          }
-          const unsigned idx = entry_index(k.base[0] + xo, k.base[1] + yo, k.base[2] + zo, G, T, hashed);
-          const float2 v = tab[idx];
-          acc.x += w * v.x;
-          acc.y += w * v.y;
-        }
-    enc_t[(int64_t)(2 * level) * M + m] = acc.x;
-    enc_t[(int64_t)(2 * level + 1) * M + m] = acc.y;
-  }
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x)
+    gather_sample(d, level, G, T, hashed, tab, x, u, M, enc_t, m);
+}
+
+// The same gather with the (level, sample chunk) -> workgroup mapping chosen per XCD.  Workgroups are dealt to the
+// eight XCDs round-robin (workgroup i runs on XCD i % 8) and every XCD has its own 4 MiB L2, so with a plain
+// (chunk, level) grid every level's table is pulled from HBM into all eight L2s.  Here the work of all levels is laid
+// out on a line (level after level, chunk after chunk, each chunk weighted by its level's cost) and cut into eight
+// equal pieces: an XCD sweeps its piece in order, so a table is fetched by one XCD — two when a cut runs through the
+// level — and the pieces end together.  Only speed depends on the dispatch order, not the result.
+constexpr int kXcds = 8;
+constexpr int kMaxXcdSegs = kMaxLevels + kXcds;
+struct XcdPlan {
+  int n_segs;
+  int first_seg[kXcds + 1];     // segments of XCD x: first_seg[x] .. first_seg[x + 1] - 1
+  int seg_level[kMaxXcdSegs];
+  int seg_chunk0[kMaxXcdSegs];  // first 256-sample chunk of the segment
+  int seg_chunks[kMaxXcdSegs];
+};
+__global__ __launch_bounds__(256) void hashgrid_fwd_xcd_kernel(HashGridDesc d, XcdPlan plan,
+                                                               const float* __restrict__ tables,
+                                                               const float* __restrict__ x, const float* __restrict__ u,
+                                                               int64_t M, float* __restrict__ enc_t) {
+  const int xcd = blockIdx.x % kXcds;
+  int slot = blockIdx.x / kXcds;
+  int seg = plan.first_seg[xcd];
+  const int seg_end = plan.first_seg[xcd + 1];
+  while (seg < seg_end && slot >= plan.seg_chunks[seg]) slot -= plan.seg_chunks[seg++];
+  if (seg >= seg_end) return;
+  const int level = plan.seg_level[seg];
+  const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
+  const float2* __restrict__ tab = reinterpret_cast<const float2*>(tables + d.table_offset[level]);
+  const int64_t m = ((int64_t)plan.seg_chunk0[seg] + slot) * 256 + threadIdx.x;
+  if (m < M) gather_sample(d, level, G, T, hashed, tab, x, u, M, enc_t, m);
 }
 
 // g_tables[level][idx][f] += w * g_enc_t[(2*level+f)*M + m].  Levels whose whole table fits in LDS
@@ -573,6 +612,78 @@ static bool lds_staging_enabled() {
   return on;
 }
 
+// LNRF_HASHGRID_XCD=0 in the environment selects the plain (chunk, level) grid of the gather (A/B measurements)
+static bool xcd_mapping_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("LNRF_HASHGRID_XCD");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
+// Relative cost of one sample of a level in the gather, measured alone at 786,432 samples (tools/
+// hashgrid_level_probe.py): dense levels 12 us, hashed levels 17 us at 4 cells per entry, 27 us at 32, 31 us beyond
+// (more and more of the 8 corners fall into different cache lines).
+static double gather_cost(const HashGridDesc& d, int l) {
+  if (!d.hashed[l]) return 12.0;
+  const double cells = (double)d.grid_size[l] * d.grid_size[l] * d.grid_size[l] / (double)d.table_size[l];
+  return cells <= 4.0 ? 17.0 : (cells <= 32.0 ? 27.0 : 31.0);
+}
+
+static XcdPlan make_xcd_plan(const HashGridDesc& d, const LevelList& levels, int64_t m, unsigned* grid) {
+  XcdPlan p;
+  const int chunks = (int)((m + 255) / 256);
+  double total = 0.0;
+  for (int i = 0; i < levels.n; ++i) total += gather_cost(d, levels.level[i]) * chunks;
+  const double share = total / kXcds;
+  p.n_segs = 0;
+  int xcd = 0, li = 0, next_chunk = 0, max_slots = 0, slots = 0;
+  double filled = 0.0;
+  p.first_seg[0] = 0;
+  while (li < levels.n) {
+    const double c = gather_cost(d, levels.level[li]);
+    // chunks of this level that still fit into the XCD's share (the last XCD takes whatever is left)
+    int take = chunks - next_chunk;
+    if (xcd < kXcds - 1) {
+      const int fit = (int)((share - filled) / c + 0.5);
+      if (fit < take) take = fit;
+    }
+    if (take > 0) {
+      p.seg_level[p.n_segs] = levels.level[li];
+      p.seg_chunk0[p.n_segs] = next_chunk;
+      p.seg_chunks[p.n_segs] = take;
+      ++p.n_segs;
+      next_chunk += take;
+      filled += take * c;
+      slots += take;
+    }
+    if (next_chunk >= chunks) {
+      ++li;
+      next_chunk = 0;
+    } else {  // the XCD is full: the rest of the level goes to the next one
+      if (slots > max_slots) max_slots = slots;
+      ++xcd;
+      p.first_seg[xcd] = p.n_segs;
+      filled = 0.0;
+      slots = 0;
+    }
+  }
+  if (slots > max_slots) max_slots = slots;
+  for (int x2 = xcd + 1; x2 <= kXcds; ++x2) p.first_seg[x2] = p.n_segs;
+  *grid = (unsigned)max_slots * kXcds;
+  // every chunk of every level exactly once, in order (otherwise the caller uses the plain grid)
+  int64_t covered = 0;
+  bool ok = p.n_segs <= kMaxXcdSegs;
+  for (int i = 0, s = 0; ok && i < levels.n; ++i) {
+    int at = 0;
+    while (s < p.n_segs && p.seg_level[s] == levels.level[i] && p.seg_chunk0[s] == at) at += p.seg_chunks[s++];
+    ok = at == chunks;
+    covered += at;
+  }
+  if (!ok || covered != (int64_t)chunks * levels.n) *grid = 0;
+  return p;
+}
+
 extern "C" int lnrf_hashgrid_fwd(const lnrf_hashgrid_desc* desc, const float* tables, const float* x, int64_t m,
                                  float* enc_t, lnrf_stream_t stream) {
   return lnrf_hashgrid_jvp(desc, tables, x, nullptr, m, enc_t, stream);
@@ -595,7 +706,17 @@ extern "C" int lnrf_hashgrid_jvp(const lnrf_hashgrid_desc* desc, const float* ta
       staged.level[staged.n++] = l;
     else direct.level[direct.n++] = l;
   }
-  if (direct.n > 0) {
+  if (direct.n > 0 && xcd_mapping_enabled() && (m + 255) / 256 * direct.n <= (int64_t)1 << 28) {
+    unsigned grid = 0;
+    const XcdPlan plan = make_xcd_plan(d, direct, m, &grid);
+    if (grid == 0) {
+      set_error("hashgrid: inconsistent XCD plan");
+      return LNRF_ERR_ARG;
+    }
+    hipLaunchKernelGGL(hashgrid_fwd_xcd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d, plan, tables, x, u, m,
+                       enc_t);
+    LNRF_LAUNCH_CHECK();
+  } else if (direct.n > 0) {
     int64_t bx = (m + 255) / 256;
     if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(hashgrid_fwd_kernel<false>, dim3((unsigned)bx, (unsigned)direct.n), dim3(256), 0,
