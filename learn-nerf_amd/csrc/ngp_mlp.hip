@@ -106,6 +106,10 @@ constexpr int kNgpStageStep = 8 * kFragBytes;                 // fused mode: sta
 constexpr int kNgpGmaxOff = kNgpLds + kWaves * kNgpStageStep;    // fused mode: 8 running maxima per lane (32 B)
 constexpr int kNgpFusedLds = kNgpGmaxOff + kThreads * 32;        // 129 KiB: one persistent workgroup per CU
 
+#ifdef LNRF_TIMELINE
+__device__ unsigned long long* g_ngp_timeline_buf = nullptr;  // 8 waves x 1024 stamps (debug build only)
+#endif
+
 template <int NE, bool BWD, bool FUSED = false>
 __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     const char* __restrict__ packed, const float* __restrict__ enc_t, const float* __restrict__ d_g, int lf,
@@ -158,19 +162,44 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
   const int64_t tile = group * kWaves + wave;
   const int64_t m = tile * kTileCols + c;
   const bool valid = m < M;
+  using Seq = NgpSeq<NE, BWD>;
+  Ring<(Seq::count + kStageFrags - 1) / kStageFrags, Seq> ring;
+#ifdef LNRF_TIMELINE
+  ring.tl.buf = g_ngp_timeline_buf;
+  ring.tl.n = 0;
+  ring.tl.on = FUSED && NE == 2 && g_ngp_timeline_buf != nullptr && blockIdx.x == gridDim.x / 2 &&
+               group == (int64_t)blockIdx.x + 2 * (int64_t)gridDim.x;
+#endif
+  LNRF_TL_STAMP(ring);  // 0: group start
   if constexpr (FUSED) __syncthreads();  // previous group's LDS reads (ring, staging) are finished
+  LNRF_TL_STAMP(ring);  // 1: after the top barrier
 
-  // encoding fragments: k slot (ks, h, j) <-> feature 16 ks + 8 (j >> 2) + 4 h + (j & 3) (row of enc_t)
+  // encoding fragments: k slot (ks, h, j) <-> feature 16 ks + 8 (j >> 2) + 4 h + (j & 3) (row of enc_t).
+  // All loads are issued before the first use: clamped addresses instead of branches, and the row stride re-read
+  // through an opaque copy so that the 16 row addresses are computed here instead of being hoisted out of the group
+  // loop and spilled (that version waited for 32 scratch / global round trips in a row: 12 us of a 32 us group).
+  int64_t Ms = M;
+  if constexpr (FUSED) asm volatile("" : "+s"(Ms));
+  const int64_t mm = valid ? m : M - 1;
+  float ev[NE][8];
+  static_for<NE>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int feat = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+      ev[ks][j] = enc_t[(int64_t)(feat < lf ? feat : lf - 1) * Ms + mm];
+    }
+  });
   bf16x8 ef[NE];
   static_for<NE>([&](auto ks_) {
     constexpr int ks = decltype(ks_)::value;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int feat = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
-      const float v = (valid && feat < lf) ? enc_t[(int64_t)feat * M + m] : 0.0f;
-      ef[ks][j] = (__bf16)v;
+      ef[ks][j] = (__bf16)((valid && feat < lf) ? ev[ks][j] : 0.0f);
     }
   });
+  LNRF_TL_STAMP(ring);  // 2: encoding loaded and converted
   float pd[3] = {0, 0, 0};
   float gy4[3] = {0, 0, 0}, g_dens = 0.0f;
   if (valid) {
@@ -182,16 +211,17 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
       g_dens = g_density[m];
     }
   }
+  LNRF_TL_STAMP(ring);  // 3: direction / output gradients requested
   __syncthreads();
+  LNRF_TL_STAMP(ring);  // 4: after the barrier
 
-  using Seq = NgpSeq<NE, BWD>;
-  Ring<(Seq::count + kStageFrags - 1) / kStageFrags, Seq> ring;
   const char* wstream = packed;
   if constexpr (FUSED) asm volatile("" : "+s"(wstream));  // keep the stage addresses out of the group loop's preheader
   ring.stream = wstream;
   ring.wave = wave;
   ring.lane = lane;
   ring.prologue();
+  LNRF_TL_STAMP(ring);  // 5: ring prologue done
 
   // sinusoidal direction embedding (model.py:65-77): feature e = 8 coord + 4 is_cos + freq, slot order = e
   bf16x8 de[2];
@@ -226,7 +256,9 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     constexpr int NXF = decltype(nxf_)::value, NYF = decltype(nyf_)::value;
     constexpr int NI = NXF / 2, NO = NYF / 2, NT = NI * NO;  // tiles of this layer's dW
     constexpr int STEPS = 2 * NT;                            // 4 waves = NT tiles x (4 / NT) k-parts of 8 / (4 / NT) steps
+    LNRF_TL_STAMP(ring);                                     // staged, arrive
     __syncthreads();                                         // all 8 tiles staged
+    LNRF_TL_STAMP(ring);                                     // released
     if ((wave >> 2) == HALF) {
       const int w4 = wave & 3;
       const int tile_id = w4 % NT, part = w4 / NT;
@@ -246,7 +278,9 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
         }
       }
     }
+    LNRF_TL_STAMP(ring);  // weight-gradient MFMAs issued
     __syncthreads();  // staging area free for the next layer
+    LNRF_TL_STAMP(ring);  // released
   };
 
   bf16x8 h0[4], o16, c1[4], c2[4];
@@ -424,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
           for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
             if (valid && row < lf) {
-              g_enc_t[(int64_t)row * M + m] = acc[q];
+              g_enc_t[(int64_t)row * Ms + m] = acc[q];  // Ms: addresses formed here, not hoisted and spilled
               tmax[q >> 1] = fmaxf(tmax[q >> 1], fabsf(acc[q]));
             }
           }
@@ -438,6 +472,7 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
             for (int i = 0; i < 8; ++i) gmax[i] = fmaxf(gmax[i], tmax[i]);
           }
         });
+  LNRF_TL_STAMP(ring);  // group end
   }
   }  // group loop
   if constexpr (BWD) {
@@ -777,3 +812,11 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
+
+#ifdef LNRF_TIMELINE
+// debug library only (tools/build_timeline.sh): where the stamped workgroup of the fused backward writes its stamps
+extern "C" int lnrf_debug_set_ngp_timeline(void* buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(lnrf::g_ngp_timeline_buf), &buf, sizeof(buf));
+  return e == hipSuccess ? LNRF_OK : lnrf::hip_fail(e, "hipMemcpyToSymbol(g_ngp_timeline_buf)");
+}
+#endif
