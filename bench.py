@@ -112,6 +112,49 @@ def self_launch(n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def comm_abi_probe(dist, rank, world, local_rank, device):
+    """Exercise the C-ABI RCCL entries (lnrf_comm_*) across the real ranks: the same vector reduced through them
+    must equal the closed-form sum.  Called by every rank AFTER the timed region and after every other measurement,
+    so that it can never disturb them: the unique id is agreed on collectively (a failure on rank 0 reaches every
+    rank as None) and the communicator part runs in a daemon thread that the main thread abandons after 60 s — the
+    caller then prints its line and leaves with os._exit, without another device synchronisation."""
+    import threading
+
+    from learn_nerf import parallel as _par
+
+    uid = None
+    if rank == 0:
+        try:
+            uid = _par.AbiComm.new_unique_id()
+        except Exception:
+            uid = None
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return "unavailable: lnrf_comm_get_unique_id failed on rank 0", True
+    result = {}
+
+    def _probe():
+        try:
+            torch.cuda.set_device(local_rank)
+            comm = _par.AbiComm(box[0], rank, world)
+            probe = torch.arange(4096, dtype=torch.float32, device=device) * (rank + 1)
+            comm.all_reduce_sum_(probe)
+            torch.cuda.synchronize()
+            expect = torch.arange(4096, dtype=torch.float32, device=device) * (world * (world + 1) / 2)
+            result["msg"] = "ok" if torch.equal(probe, expect) else "MISMATCH vs the expected sum"
+            comm.destroy()
+        except Exception as exc:
+            result["msg"] = f"{type(exc).__name__}: {exc}"
+
+    th = threading.Thread(target=_probe, daemon=True)
+    th.start()
+    th.join(timeout=60.0)
+    if "msg" in result:
+        return result["msg"], True
+    return "timeout after 60 s (abandoned)", False
+
+
 def build_loop(workload, precision, table_log2, device):
     from learn_nerf.model import NeRFModel
     from learn_nerf.train import TrainLoop
@@ -286,46 +329,6 @@ def main():
 
     from learn_nerf.rng import Key
 
-    comm_abi_check = None
-    if world > 1:
-        # Exercise the C-ABI RCCL entries (lnrf_comm_*) across the real ranks, outside the timed region: the same
-        # vector reduced through them and through torch.distributed must agree.  It must never take the benchmark
-        # down: the unique id is agreed on collectively (a failure on rank 0 reaches every rank as None) and the
-        # communicator part runs in a daemon thread that the main thread abandons after 90 s.
-        import threading
-
-        from learn_nerf import parallel as _par
-
-        uid = None
-        if rank == 0:
-            try:
-                uid = _par.AbiComm.new_unique_id()
-            except Exception:
-                uid = None
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
-            comm_abi_check = "unavailable: lnrf_comm_get_unique_id failed on rank 0"
-        else:
-            result = {}
-
-            def _probe():
-                try:
-                    torch.cuda.set_device(local_rank)
-                    comm = _par.AbiComm(box[0], rank, world)
-                    probe = torch.arange(4096, dtype=torch.float32, device=device) * (rank + 1)
-                    comm.all_reduce_sum_(probe)
-                    torch.cuda.synchronize()
-                    expect = torch.arange(4096, dtype=torch.float32, device=device) * (world * (world + 1) / 2)
-                    result["msg"] = "ok" if torch.equal(probe, expect) else "MISMATCH vs the expected sum"
-                    comm.destroy()
-                except Exception as exc:
-                    result["msg"] = f"{type(exc).__name__}: {exc}"
-
-            th = threading.Thread(target=_probe, daemon=True)
-            th.start()
-            th.join(timeout=90.0)
-            comm_abi_check = result.get("msg", "timeout after 90 s (abandoned)")
     for i in range(args.warmup):
         step(Key(i, ray_offset=rank * n), batch)
     barrier()
@@ -419,7 +422,6 @@ def main():
             step_mfma=dict(achieved=round(step_tflops, 1), peak=PEAK_BF16_FLOPS / 1e12, unit="TFLOP/s",
                            frac=round(step_tflops / (PEAK_BF16_FLOPS / 1e12), 4),
                            note="whole step per GPU: ray-samples/s x 4,641,792 algorithmic FLOP (SURVEY 8d)"),
-            comm_abi_check=comm_abi_check,
             kernels=fams,
             losses={k: round(float(v), 5) for k, v in log.items()},
         )
@@ -463,10 +465,19 @@ def main():
                     out["other_workloads"][wl] = dict(error=f"{type(exc).__name__}: {exc}")
         if world == 1 and not args.no_cpu_baseline and args.workload == "nerf":
             out["cpu_baseline"] = cpu_baseline()
+    clean = True
+    if world > 1:  # last: nothing measured above can be disturbed by it (rank 0 arrives here after its extra timings)
+        msg, clean = comm_abi_probe(dist, rank, world, local_rank, device)
+        if rank == 0:
+            out["comm_abi_check"] = msg
+    if rank == 0:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+    if not clean:  # an abandoned probe may have left a spinning collective behind: no further device calls
+        sys.stderr.flush()
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -17,7 +17,7 @@ import os
 import warnings
 from collections import OrderedDict
 from dataclasses import dataclass, field
-from typing import Any, Dict, List, Optional, Tuple
+from typing import ClassVar, Any, Dict, List, Optional, Tuple
 
 import torch
 
@@ -142,6 +142,11 @@ class NeRFModel(ModelBase):
     # "split" = separate chain and weight-gradient launches through HBM (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
     backward_kernel: str = os.environ.get("LNRF_NERF_BACKWARD", "split")
     tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
+    # TrainLoop may run the coarse backward on a second stream beside the fine forward; for this model every kernel
+    # already fills all 256 CUs at one workgroup per CU, so the two streams only time-slice (5.012 / 5.020 ms without,
+    # 5.001 / 5.003 ms with it, same box) while the per-kernel HIP-event and rocprof durations double.  Off by default
+    # so that the kernel timers of bench.py stay meaningful; LNRF_OVERLAP_BACKWARD=1 turns it on.
+    overlap_backward_hint: ClassVar[bool] = False
 
     _pack_cache: Any = field(default=None, repr=False, compare=False)
     _pack_generation: int = field(default=0, repr=False, compare=False)

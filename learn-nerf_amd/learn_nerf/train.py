@@ -95,8 +95,9 @@ class TrainLoop:
         self._scalars_dirty = False  # lnrf_step_log leaves the accumulators zeroed for the next step
         # The coarse model's backward depends on nothing of the fine pass (fine sampling carries no gradient,
         # render.py:211-257), so it runs on a second HIP stream beside the fine forward / backward and is joined
-        # before the optimizer (measured: vanilla 5.07 -> 5.00 ms, Ref-NeRF 11.03 -> 10.79 ms per step; the hash-grid
-        # model opts out through its overlap_backward_hint: 2.30 -> 2.33 ms).  LNRF_OVERLAP_BACKWARD=0 / 1 overrides.
+        # before the optimizer (measured: Ref-NeRF 11.03 -> 10.79 ms per step; NeRFModel and the hash-grid model opt
+        # out through overlap_backward_hint: 5.015 -> 5.002 ms is within noise and doubles the per-kernel timings,
+        # hash grid 2.30 -> 2.33 ms).  LNRF_OVERLAP_BACKWARD=0 / 1 overrides.
         env = os.environ.get("LNRF_OVERLAP_BACKWARD")
         want = (env != "0") if env is not None else bool(getattr(coarse, "overlap_backward_hint", True))
         self.overlap_backward = torch.device(self.device).type == "cuda" and coarse is not fine and want
