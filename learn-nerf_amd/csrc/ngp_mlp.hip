@@ -102,6 +102,32 @@ struct NgpWgradEpi {
     return r16 < nv ? base + r16 : -1;
   }
 };
+// k-parts of the fused mode per weight-gradient problem (host table order: Dense_3, Dense_2, Dense_1, Dense_4,
+// Dense_0): a layer with NT < 4 dW tiles is dealt to its four waves as NT tiles x 4 / NT parts of the group's 256
+// evaluations, and every part has its own row in the partial-sum buffer
+constexpr int kNgpMaxParts = 4;
+__host__ __device__ constexpr int ngp_wgrad_parts(int problem) { return (problem == 0 || problem == 1) ? 1 : 2; }
+struct NgpPartsPlan {
+  int lo[kNgpLayers], hi[kNgpLayers], parts[kNgpLayers];  // float range [lo, hi) relative to dense_offset
+};
+// grads[dense_off + p] += sum over workgroups and the layer's k-parts of wparts[(wg, part)][p]; blockIdx.y = slice of
+// the workgroup rows (a few atomics per address instead of one per workgroup)
+__global__ __launch_bounds__(256) void ngp_wparts_reduce_kernel(const float* __restrict__ wparts, int n_wg, int pstride,
+                                                                int n_params, NgpPartsPlan plan,
+                                                                float* __restrict__ grads_dense) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_params) return;
+  int parts = 0;
+#pragma unroll
+  for (int l = 0; l < kNgpLayers; ++l)
+    if (p >= plan.lo[l] && p < plan.hi[l]) parts = plan.parts[l];
+  const int w0 = (int)((int64_t)n_wg * blockIdx.y / gridDim.y), w1 = (int)((int64_t)n_wg * (blockIdx.y + 1) / gridDim.y);
+  float acc = 0.0f;
+  for (int w = w0; w < w1; ++w)
+    for (int q = 0; q < parts; ++q) acc += wparts[((int64_t)w * kNgpMaxParts + q) * pstride + p];
+  if (parts > 0) atomicAdd(grads_dense + p, acc);
+}
+
 constexpr int kNgpStageStep = 8 * kFragBytes;                 // fused mode: staging bytes per wave (<= 8 fragments per layer)
 constexpr int kNgpGmaxOff = kNgpLds + kWaves * kNgpStageStep;    // fused mode: 8 running maxima per lane (32 B)
 constexpr int kNgpFusedLds = kNgpGmaxOff + kThreads * 32;        // 129 KiB: one persistent workgroup per CU
@@ -116,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     int64_t M, int64_t n_tiles, float* __restrict__ density, float* __restrict__ rgb,
     const float* __restrict__ g_density, const float* __restrict__ g_rgb, char* __restrict__ scratch,
     float* __restrict__ g_enc_t, float* __restrict__ lmax_parts = nullptr, NgpWgradArgs wargs = NgpWgradArgs{},
-    float* __restrict__ grads = nullptr) {
+    float* __restrict__ wparts = nullptr, int pstride = 0, int64_t dense_off = 0) {
   static_assert(!FUSED || BWD, "FUSED is a backward mode");
   // backward: running max |d loss / d enc| of the rows this lane writes, 8 slots (rows 4h + 8j + {0,1} / + {2,3} are
   // the two features of levels 2h + 4j / 2h + 4j + 1): the fixed-point scale of the scatter pass.  The persistent
@@ -492,30 +518,37 @@ __global__ __launch_bounds__(kThreads) void ngp_mlp_kernel(
     }
   }
   if constexpr (FUSED) {
-    // the launch's share of dW: one tile per layer and wave, added once (fp32 atomics)
+    // The launch's share of dW: every wave stores its tile (and bias sums) ONCE, with plain stores, into the row of its
+    // (workgroup, k-part) in `wparts`; ngp_wparts_reduce_kernel folds the rows into the gradient vector.  (fp32
+    // atomics straight into the gradient — 256 workgroups hitting the same 10 K addresses — cost 76 us per launch,
+    // half of the coarse model's backward: same-line memory atomics retire one after the other.)
     const int colr = lane & 31, hh = lane >> 5;
     auto flush = [&](auto p_, auto slot_, auto half_, auto nxf_, auto nyf_) {
       constexpr int P = decltype(p_)::value, SLOT = decltype(slot_)::value, HALF = decltype(half_)::value;
       constexpr int NXF = decltype(nxf_)::value, NYF = decltype(nyf_)::value;
       constexpr int NO = NYF / 2, NT = (NXF / 2) * NO;
+      static_assert(4 / NT == ngp_wgrad_parts(P), "k-parts per layer: host table of the reduce launch");
       if ((wave >> 2) != HALF) return;
       const NgpWgradProblem& pb = wargs.p[P];
-      const int tile_id = (wave & 3) % NT;
+      const int tile_id = (wave & 3) % NT, part = (wave & 3) / NT;
       const int it = tile_id / NO, ot = tile_id % NO;
       int out_idx = -1, out_dim = 1;
       int64_t w_off = 0, b_off = 0;
       NgpWgradEpi::cols(pb, ot, colr, out_idx, out_dim, w_off, b_off);
+      float* __restrict__ row = wparts + ((int64_t)blockIdx.x * kNgpMaxParts + part) * pstride;
+      w_off -= dense_off;  // rows hold the Dense parameters only
+      b_off -= dense_off;
       if (it == 0) {
         float sacc = wbias[SLOT];
         sacc += __shfl_xor(sacc, 32, 64);
-        if (hh == 0 && out_idx >= 0) atomicAdd(grads + b_off + out_idx, sacc);
+        if (hh == 0 && out_idx >= 0) row[b_off + out_idx] = sacc;
       }
       static_for<16>([&](auto q_) {
         constexpr int qq = decltype(q_)::value;
         const int r = (qq & 3) + 8 * (qq >> 2) + 4 * hh;
         const int f = 2 * it + (r >> 4);
         const int in_idx = NgpWgradEpi::row(pb, f, r & 15);
-        if (out_idx >= 0 && in_idx >= 0) atomicAdd(grads + w_off + (int64_t)in_idx * out_dim + out_idx, wacc[SLOT][qq]);
+        if (out_idx >= 0 && in_idx >= 0) row[w_off + (int64_t)in_idx * out_dim + out_idx] = wacc[SLOT][qq];
       });
     };
     // (problem index of the host table, accumulator slot, workgroup half, X fragments, dy fragments)
@@ -764,19 +797,38 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
     int64_t nb = n_tiles / kWaves;
     if (nb > cus) nb = cus;
     const dim3 pgrid((unsigned)nb);
+    // partial dW rows (workgroup, k-part) live where the two-launch path keeps its dumps: nb <= n_tiles / 8 rows of
+    // 4 x pstride floats against 8 x 34 KiB of dump room per workgroup
+    NgpPartsPlan plan;
+    for (int i = 0; i < kNgpLayers; ++i) {
+      const int layer = i == 0 ? 3 : (i == 1 ? 2 : (i == 2 ? 1 : (i == 3 ? 4 : 0)));  // problem i of the table above
+      plan.lo[i] = (int)(off.w[layer] - desc->dense_offset);
+      plan.hi[i] = (int)(off.b[layer] - desc->dense_offset) + ngp_out_dim(layer);
+      plan.parts[i] = ngp_wgrad_parts(i);
+    }
+    const int n_params = plan.hi[3];  // Dense_4 is the last layer of the vector
+    const int pstride = (n_params + 63) / 64 * 64;
+    if ((int64_t)nb * kNgpMaxParts * pstride * (int64_t)sizeof(float) > (int64_t)kNgpSlots * n_tiles * kFragBytes) {
+      set_error("lnrf_ngp_mlp_bwd: scratch too small for the partial weight gradients");
+      return LNRF_ERR_ARG;
+    }
+    float* wparts = reinterpret_cast<float*>(scratch);
     if (desc->enc_dim <= 16) {
       rc = ngp_ensure_lds(ngp_mlp_kernel<1, true, true>, kNgpFusedLds);
       if (rc) return rc;
       hipLaunchKernelGGL((ngp_mlp_kernel<1, true, true>), pgrid, block, kNgpFusedLds, st, (const char*)packed, enc_t, d,
                          (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t,
-                         lmax_parts, a, grads);
+                         lmax_parts, a, wparts, pstride, (int64_t)desc->dense_offset);
     } else {
       rc = ngp_ensure_lds(ngp_mlp_kernel<2, true, true>, kNgpFusedLds);
       if (rc) return rc;
       hipLaunchKernelGGL((ngp_mlp_kernel<2, true, true>), pgrid, block, kNgpFusedLds, st, (const char*)packed, enc_t, d,
                          (int)desc->enc_dim, m, n_tiles, nullptr, nullptr, g_density, g_rgb, nullptr, g_enc_t,
-                         lmax_parts, a, grads);
+                         lmax_parts, a, wparts, pstride, (int64_t)desc->dense_offset);
     }
+    LNRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ngp_wparts_reduce_kernel, dim3((unsigned)((n_params + 255) / 256), 8), dim3(256), 0, st, wparts,
+                       (int)nb, pstride, n_params, plan, grads + desc->dense_offset);
     LNRF_LAUNCH_CHECK();
     if (lmax_parts) {
       hipLaunchKernelGGL(ngp_level_max_kernel, dim3(1), dim3(256), 0, st, lmax_parts, (int)nb, n_levels,

@@ -22,6 +22,7 @@ from .model import ModelBase
 from .params import lecun_normal_
 
 F32 = torch.float32
+POISON_SCRATCH = False  # tests set this: scratch buffers are filled with 0xFF bytes (NaN) before the kernels run
 
 
 def _level_rows(grid_size: int, table_size: int) -> Tuple[int, bool]:
@@ -184,6 +185,8 @@ class InstantNGPModel(ModelBase):
         with _prof.section(f"{self.tag}_mlp_bwd"):
             nbytes = L.lib().lnrf_ngp_mlp_scratch_bytes(ctypes.byref(desc), m)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            if POISON_SCRATCH:  # tests: every word the kernels read back must have been written by them
+                scratch.fill_(0xFF)
             g_enc_t = torch.empty((lf, m), dtype=F32, device=dev)
             level_absmax = torch.zeros(lf // 2, dtype=F32, device=dev)  # the scatter's fixed-point scale per level
             gd = g_density.reshape(-1).contiguous()

@@ -103,8 +103,10 @@ def test_ngp_model_forward_backward(levels, table):
 
 
 @pytest.mark.parametrize("levels,table,m", [(6, 2 ** 12, 2500), (16, 2 ** 14, 4133), (3, 2 ** 10, 31)])
-def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m):
+def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m, monkeypatch):
     """
+    The backward's scratch buffer (partial weight-gradient rows of the fused kernel) is poisoned with NaN bytes first:
+    every word the reduce launch folds must have been written by the backward kernel.
     lnrf_ngp_mlp_fwd / lnrf_ngp_mlp_bwd (bf16 MFMA operands, fp32 accumulate) against the oracle with the same
     operand rounding.  Forward: 2e-3 (bf16 rounding boundaries of intermediate activations); gradients: 3e-2
     relative L2 (ReLU mask flips + bf16 dy operands), as for the fused NeRFModel.  The distance to the exact
@@ -112,6 +114,9 @@ def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m):
     """
     from oracle.model import bf16_round
 
+    import learn_nerf.instant_ngp as NGP
+
+    monkeypatch.setattr(NGP, "POISON_SCRATCH", True)
     model, params, flat = make_model(levels, table, precision="bf16")
     assert model._use_fused()
     x, d, gen = points(m, seed=levels)
@@ -134,6 +139,7 @@ def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m):
     model.backward(ctx, g_d.cuda(), g_c.cuda(), None, grad)
     nt = model.encoding().num_table_floats()
     got = grad.cpu()
+    assert torch.isfinite(got).all()
     for name, a, b in (("tables", got[:nt], g_ref[:nt]), ("mlp", got[nt:], g_ref[nt:])):
         rel = ((a - b).norm() / b.norm()).item()
         print(f"   {name}: rel L2 err vs bf16-operand oracle {rel:.2e}")
