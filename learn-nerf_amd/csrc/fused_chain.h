@@ -422,6 +422,9 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
     if (i + 1 < iters) compute(c1);
   }
 
+#ifdef LNRF_NO_FLUSH
+  if (n_tiles >= 0) return;  // timing experiment only (results are wrong): what the epilogue below costs
+#endif
   // epilogue: atomically add the partial dW tiles / bias sums
   const int colr = lane & 31, hh = lane >> 5;
   static_for<TO>([&](auto b_) {

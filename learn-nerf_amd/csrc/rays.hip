@@ -351,7 +351,7 @@ __global__ void composite_bwd_kernel(const float* __restrict__ ts, const float* 
 }
 
 // fine_sampling (render.py:211-257). One wave per ray; LDS per wave: xs[tc+1], ys[tc+1],
-// comb[tc+tf].  The final jnp.sort is an exact rank sort (no sortedness assumed).
+// comb[tc+tf].  The final jnp.sort is exact for any input (merge ranks when both lists are in order, rank count otherwise).
 __global__ void fine_sample_kernel(const float* __restrict__ ts_c, const float* __restrict__ t_min,
                                    const float* __restrict__ t_max,
                                    const float* __restrict__ density_c, int64_t n_rays, int tc,
@@ -420,8 +420,31 @@ __global__ void fine_sample_kernel(const float* __restrict__ ts_c, const float* 
   }
   if (!combine) return;
   __syncthreads();
-  // exact stable rank sort of comb[0..tc+tf) (render.py:253-255)
+  // exact stable sort of comb[0..tc+tf) (render.py:253-255).  The coarse ts (stratified) and the new ts (a monotone
+  // map of increasing CDF arguments) are each already in order, so an element's rank is its own index plus a binary
+  // search in the other list (ties: the coarse element first, as in the stable sort); the wave checks the two orders
+  // and falls back to the O(T^2) rank count for anything else (unsorted caller-supplied ts, NaN).
   const int tot = tc + tf;
+  bool in_order = true;
+  for (int e = lane; e + 1 < tot; e += 64)
+    if (e + 1 != tc) in_order &= comb[e] <= comb[e + 1];
+  if (__all(in_order)) {
+    for (int e = lane; e < tot; e += 64) {
+      const float x = comb[e];
+      const bool first = e < tc;
+      // first list: count of new ts < x (lower bound); second list: count of coarse ts <= x (upper bound)
+      const float* other = first ? comb + tc : comb;
+      int lo = 0, hi = first ? tf : tc;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float y = other[mid];
+        if (first ? (y < x) : (y <= x)) lo = mid + 1; else hi = mid;
+      }
+      const int rank = (first ? e : e - tc) + lo;
+      if (live) ts_out[n * tot + rank] = x;
+    }
+    return;
+  }
   for (int e = lane; e < tot; e += 64) {
     const float x = comb[e];
     int rank = 0;

@@ -162,6 +162,27 @@ def test_fine_sample(n, tc, tf):
     assert frac_close > 0.99
 
 
+def test_fine_sample_sorts_unsorted_and_tied_input():
+    """lnrf_fine_sample's final sort (render.py:253-255) must not depend on the coarse ts being in order: shuffled
+    coarse ts take the rank-count path, ties between the two lists (density 0 everywhere -> flat CDF -> new ts pile up
+    on bin edges) take the merge path; both must equal torch.sort bit for bit."""
+    from learn_nerf import ops
+
+    n, tc, tf = 33, 64, 128
+    rays, gen = make_rays(n)
+    g = lambda x: x.cuda()
+    t_min, t_max, mask, ts = ops.ray_aabb_stratified(g(rays), BBOX_MIN, BBOX_MAX, tc, u=g(torch.rand(n, tc, generator=gen)))
+    uf = g(torch.rand(n, tf, generator=gen))
+    perm = torch.stack([torch.randperm(tc, generator=gen) for _ in range(n)]).cuda()
+    cases = {"shuffled": (torch.gather(ts, 1, perm), g((torch.rand(n, tc, generator=gen) * 5).float())),
+             "ties": (ts, torch.zeros(n, tc, device="cuda"))}
+    for name, (ts_in, dens) in cases.items():
+        out = ops.fine_sample(ts_in, t_min, t_max, dens, tf, u=uf)
+        new_only = ops.fine_sample(ts_in, t_min, t_max, dens, tf, u=uf, combine=False)
+        want = torch.sort(torch.cat([ts_in, new_only], 1), 1).values
+        assert torch.equal(out, want), name
+
+
 @pytest.mark.parametrize("n,t,n_aux", [(40, 64, 0), (33, 192, 2), (7, 70, 1)])
 def test_composite_bwd_matches_autograd(n, t, n_aux):
     from learn_nerf import ops
