@@ -206,14 +206,34 @@ __device__ __forceinline__ void stream_store(char* p, uint4 v) {
   __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
 }
 
+// Byte offset of fragment (slot, tile) in a dump buffer.  n_slots == 0: slot-major [slot][tile][1 KiB] (a slot's tiles
+// are contiguous; a wave's dumps of one tile are n_tiles KiB apart).  n_slots > 0: tile-major [tile][slot][1 KiB] (a
+// tile's n_slots fragments are one contiguous block: the dumping wave writes through one block front to back, and a
+// weight-gradient workgroup reads its layer's 16 + 16 KiB out of consecutive blocks).
+// With LNRF_DUMP_GROUP = G > 1 (a power of two dividing the 8 tiles of a workgroup) the blocks hold G tiles each:
+// [tile / G][slot][tile % G][1 KiB], i.e. the 8 waves of a dumping workgroup fill G KiB runs per slot.
+#ifndef LNRF_DUMP_GROUP
+#define LNRF_DUMP_GROUP 1
+#endif
+constexpr int kDumpGroup = LNRF_DUMP_GROUP;
+static_assert(kDumpGroup >= 1 && (kDumpGroup & (kDumpGroup - 1)) == 0 && kDumpGroup <= 8, "dump group");
+__device__ __forceinline__ int64_t dump_off(int slot, int64_t tile, int64_t n_tiles, int n_slots) {
+  if (n_slots > 0) return (((tile / kDumpGroup) * n_slots + slot) * kDumpGroup + tile % kDumpGroup) * kFragBytes;
+  return ((int64_t)slot * n_tiles + tile) * kFragBytes;
+}
 struct DumpAddr {
-  char* base;       // [slot][tile][1 KiB]
+  char* base;
   int64_t n_tiles;  // tiles in the buffer
   int64_t tile;
   int c, hh;
+  int n_slots = 0;  // 0: slot-major, else tile-major with this many slots per tile
   __device__ __forceinline__ char* at(int slot) const {
-    return base + ((int64_t)slot * n_tiles + tile) * kFragBytes + dump_lane_off(slot, c, hh);
+    return base + dump_off(slot, tile, n_tiles, n_slots) + dump_lane_off(slot, c, hh);
   }
+};
+// which layout the operand buffers of a weight-gradient launch have (slots per tile, 0 = slot-major)
+struct WgLayout {
+  int x_slots = 0, y_slots = 0;
 };
 
 // One GEMM layer of the fused chain: for each 32-row out tile, for each k-step, one MFMA.
@@ -280,9 +300,10 @@ struct WgStage {
   static constexpr int PER_WAVE = (NF + kWaves - 1) / kWaves;
   static constexpr int STEP_BYTES = NF * kFragBytes;
   static constexpr int ITER_BYTES = kWgSpi * STEP_BYTES;
-  const char* x_src;  // slot x_slot0, first tile of this K-slice, + lane*16
+  const char* x_src;  // buffer base + lane*16
   const char* y_src;
-  int64_t slot_stride;  // bytes between consecutive slots (= n_tiles KiB)
+  int x_slot0, y_slot0, x_slots, y_slots;  // first slot of the operand; slots per tile of its buffer (0: slot-major)
+  int64_t t0, n_tiles;                     // first tile of this K-slice; tiles in the buffers
   int64_t steps;        // steps in this K-slice
   int wave, lane;
   uint4 rr[kWgSpi][PER_WAVE];
@@ -301,9 +322,10 @@ struct WgStage {
       for (int q = 0; q < PER_WAVE; ++q) {
         int f = wave + kWaves * q;
         if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
-        const char* src = f < NXF ? x_src + (int64_t)f * slot_stride : y_src + (int64_t)(f - NXF) * slot_stride;
+        const char* src = f < NXF ? x_src + dump_off(x_slot0 + f, t0 + st, n_tiles, x_slots)
+                                  : y_src + dump_off(y_slot0 + f - NXF, t0 + st, n_tiles, y_slots);
         // read-once operands: non-temporal loads leave L2 / Infinity Cache to data that is reused
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + st * kFragBytes));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
         rr[u][q] = make_uint4(v[0] & keep, v[1] & keep, v[2] & keep, v[3] & keep);
       }
     }
@@ -327,7 +349,7 @@ struct WgStage {
 template <int NXF, int NYF, int WI, int WO, int SPI, class EPI, class PB>
 __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict__ save,
                                            const char* __restrict__ gdump, int64_t n_tiles,
-                                           float* __restrict__ grads) {
+                                           float* __restrict__ grads, WgLayout lay = WgLayout{}) {
   constexpr int NI = NXF / 2, NO = NYF / 2;
   constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;  // tiles per wave
   constexpr bool FULL_I = TI * WI == NI, FULL_O = TO * WO == NO;   // every wave owns TI x TO real tiles
@@ -350,9 +372,14 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
   const int64_t iters = (steps + kWgSpi - 1) / kWgSpi;
 
   Stage stg;
-  stg.x_src = save + ((int64_t)pb.x_slot0 * n_tiles + t0) * kFragBytes + lane * 16;
-  stg.y_src = gdump + ((int64_t)pb.y_slot0 * n_tiles + t0) * kFragBytes + lane * 16;
-  stg.slot_stride = n_tiles * kFragBytes;
+  stg.x_src = save + lane * 16;
+  stg.y_src = gdump + lane * 16;
+  stg.x_slot0 = pb.x_slot0;
+  stg.y_slot0 = pb.y_slot0;
+  stg.x_slots = lay.x_slots;
+  stg.y_slots = lay.y_slots;
+  stg.t0 = t0;
+  stg.n_tiles = n_tiles;
   stg.steps = steps;
   stg.wave = wave;
   stg.lane = lane;

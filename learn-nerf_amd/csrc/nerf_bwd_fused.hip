@@ -213,8 +213,8 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradProblem& pb, int flag
   const int64_t iters = n_items * IPG;
   volatile unsigned* bc = reinterpret_cast<volatile unsigned*>(&smem[kFusedBwdLds]);  // 1 word past the stage buffers
 
-  const char* x_base = save + (int64_t)pb.x_slot0 * save_tiles * kFragBytes + lane * 16;
-  const int64_t x_stride = save_tiles * kFragBytes;
+  // the forward's save buffer in either layout (fused_chain.h dump_off): slot stride / tile stride
+  const char* x_base = save + lane * 16;
   uint4 rr[2][SPI][PER_WAVE];  // two iterations of loads in flight: one iteration per memory latency is not enough
   unsigned cur_group = 0;
   __amdgpu_buffer_rsrc_t yrs = ring_rsrc(ring);
@@ -260,7 +260,7 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradProblem& pb, int flag
         if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
         if (f < NXF) {
           const u4v v = __builtin_nontemporal_load(
-              reinterpret_cast<const u4v*>(x_base + (int64_t)f * x_stride + tile * kFragBytes));
+              reinterpret_cast<const u4v*>(x_base + dump_off(pb.x_slot0 + f, tile, save_tiles, kSaveTileSlots)));
           rr[P][u][q] = make_uint4(v[0], v[1], v[2], v[3]);
         } else {
           const int off = ((y_local0 + f - NXF) * kWaves + tg) * kFragBytes + lane * 16;

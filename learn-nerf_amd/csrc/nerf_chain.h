@@ -69,7 +69,7 @@ __device__ __forceinline__ void bwd_chain_tile(RING& ring, SINK& sink, const cha
   uint4 relu_mask[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
-    relu_mask[i] = *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * save_tiles + tile) * kFragBytes +
+    relu_mask[i] = *reinterpret_cast<const uint4*>(save + dump_off(kSaveMask + i, tile, save_tiles, kSaveTileSlots) +
                                                    lane * 16);
   __syncthreads();
   ring.prologue();
@@ -213,7 +213,7 @@ struct NerfWgradEpi {
 // launches nerf_wgrad_kernel (nerf_mlp.hip) on `blocks` workgroups: X operands from xbuf, dy operands from ybuf (both
 // [slot][tile][1 KiB] dumps with n_tiles tiles per slot)
 int launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
-                      float* grads, hipStream_t stream);
+                      float* grads, hipStream_t stream, WgLayout lay = WgLayout{});
 
 // The 13 problems of one NeRFModel, heaviest first; `blocks[i]` workgroups for problem i (capped by `cap`).
 // Block budget per problem in the order: Dense_1..8 (hidden x hidden), z x dy10m, x_emb x dy0, x_emb x dy5,

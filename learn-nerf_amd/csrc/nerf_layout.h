@@ -334,6 +334,12 @@ constexpr int kGradDy11 = 0;            // 2 slots (second is zero padding)
 constexpr int kGradDy10m = 2;           // 10 slots: 8 for Dense_10 outputs, slot 8 = logit, slot 9 zero
 constexpr int kGradDy = 12;             // dy8, dy7, ..., dy0: 16 slots each, index (8 - l)
 constexpr int kGradSlots = kGradDy + 9 * 16;  // 156
+// NeRFModel dump layout: tile-major unless built with -DLNRF_DUMP_SLOT_MAJOR (A/B; see fused_chain.h dump_off)
+#ifdef LNRF_DUMP_SLOT_MAJOR
+constexpr int kSaveTileSlots = 0, kGradTileSlots = 0;
+#else
+constexpr int kSaveTileSlots = kSaveSlots, kGradTileSlots = kGradSlots;
+#endif
 NL_HD constexpr int grad_dy_slot(int l) { return kGradDy + (8 - l) * 16; }
 
 }  // namespace nl

@@ -9,6 +9,7 @@
 //            gradients dy_l and dumps them, (2) a split-K MFMA kernel reduces
 //            dW_l = X_l^T dy_l over all evaluations from the forward/backward dumps.
 // Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / positional encoding.
+#include <stdlib.h>
 #include "nerf_chain.h"
 
 namespace lnrf {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
     }
   });
 
-  DumpAddr dump{save, n_tiles, tile, c, h};
+  DumpAddr dump{save, n_tiles, tile, c, h, kSaveTileSlots};
   auto save_frag = [&](int slot, const bf16x8& f) {
     if (SAVE) stream_store(dump.at(slot), frag_to_bits(f));
   };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           if constexpr (SAVE && RELU) mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
         });
     if constexpr (SAVE && RELU) {
-      *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile) * kFragBytes + lane * 16) =
+      *reinterpret_cast<uint4*>(save + dump_off(kSaveMask + S, tile, n_tiles, kSaveTileSlots) + lane * 16) =
           make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
       mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
     }
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           if constexpr (SAVE) mask_bits[o >> 1] |= relu_bits(a1[2 * o], a1[2 * o + 1]) << (16 * (o & 1));
         } else {
           if constexpr (SAVE) {
-            *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + 8) * n_tiles + tile) * kFragBytes +
+            *reinterpret_cast<uint4*>(save + dump_off(kSaveMask + 8, tile, n_tiles, kSaveTileSlots) +
                                       lane * 16) = make_uint4(mask_bits[0], mask_bits[1], 0u, 0u);
           }
           if (h == 0 && valid) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
   ring.tl.on = g_timeline_buf != nullptr && blockIdx.x == gridDim.x / 2;
   ring.tl.stamp();
 #endif
-  GlobalDumpSink sink{DumpAddr{gdump, n_tiles, tile, lane & 31, lane >> 5}};
+  GlobalDumpSink sink{DumpAddr{gdump, n_tiles, tile, lane & 31, lane >> 5, kGradTileSlots}};
   bwd_chain_tile(ring, sink, save, n_tiles, density, rgb, g_density, g_rgb, M, tile, lane);
 }
 
@@ -451,19 +452,20 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
 // Problems are listed heaviest first so that the small ones fill the tail of the launch.
 __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, const char* __restrict__ save,
                                                               const char* __restrict__ gdump,
-                                                              int64_t n_tiles, float* __restrict__ grads) {
+                                                              int64_t n_tiles, float* __restrict__ grads,
+                                                              WgLayout lay) {
   WgradProblem pb = args.p[0];
 #pragma unroll
   for (int i = 1; i < kMaxProblems; ++i)
     if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
   switch (pb.shape) {
     // steps per barrier chosen so that every body keeps ~60 KB of loads in flight per workgroup
-    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
-    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
-    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
-    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
-    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;  // Ref-NeRF Dense_9
-    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads); break;
+    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
+    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
+    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
+    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
+    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;  // Ref-NeRF Dense_9
+    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
   }
 }
 
@@ -703,13 +705,13 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
 }
 
 int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
-                            float* grads, hipStream_t stream) {
+                            float* grads, hipStream_t stream, WgLayout lay) {
   const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_wgrad_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
   hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args, (const char*)xbuf,
-                     (const char*)ybuf, n_tiles, grads);
+                     (const char*)ybuf, n_tiles, grads, lay);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
@@ -728,10 +730,16 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   int rc;
   // weight-gradient problems: ONE launch, heaviest problems first, blocks proportional to bytes
   WgradArgs a;
-  const int blocks[13] = {48, 48, 48, 48, 47, 47, 47, 47, 39, 30, 30, 18, 15};
+  int blocks[13] = {48, 48, 48, 48, 47, 47, 47, 47, 39, 30, 30, 18, 15};
+  {
+    // experiment: LNRF_WGRAD_BLOCK_SCALE=<percent> scales the per-problem workgroup counts (default 100 = 512 total)
+    static const int pct = [] { const char* v = getenv("LNRF_WGRAD_BLOCK_SCALE"); return v ? atoi(v) : 100; }();
+    if (pct > 0 && pct != 100)
+      for (int i = 0; i < 13; ++i) blocks[i] = (blocks[i] * pct + 50) / 100 < 1 ? 1 : (blocks[i] * pct + 50) / 100;
+  }
   const int first = build_wgrad_problems(a, blocks, (n_tiles + 5) / 6);
   (void)rc;
-  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st);
+  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots});
 }
 
 #ifdef LNRF_TIMELINE
