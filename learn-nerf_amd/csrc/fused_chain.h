@@ -234,6 +234,7 @@ struct DumpAddr {
 // which layout the operand buffers of a weight-gradient launch have (slots per tile, 0 = slot-major)
 struct WgLayout {
   int x_slots = 0, y_slots = 0;
+  int interleave = 0;  // 1: split s of a problem takes tiles (i * n_blocks + s) * SPI + u instead of a contiguous range
 };
 
 // One GEMM layer of the fused chain: for each 32-row out tile, for each k-step, one MFMA.
@@ -304,6 +305,7 @@ struct WgStage {
   const char* y_src;
   int x_slot0, y_slot0, x_slots, y_slots;  // first slot of the operand; slots per tile of its buffer (0: slot-major)
   int64_t t0, n_tiles;                     // first tile of this K-slice; tiles in the buffers
+  int64_t iter_stride, t_end;              // tile of (iteration i, step u) = t0 + i * iter_stride + u, valid below t_end
   int64_t steps;        // steps in this K-slice
   int wave, lane;
   uint4 rr[kWgSpi][PER_WAVE];
@@ -314,9 +316,9 @@ struct WgStage {
   __device__ __forceinline__ void load(int64_t iter) {
 #pragma unroll
     for (int u = 0; u < kWgSpi; ++u) {
-      const int64_t step = iter * kWgSpi + u;
-      const bool ok = step < steps;
-      const int64_t st = ok ? step : 0;
+      const int64_t tl = t0 + iter * iter_stride + u;
+      const bool ok = tl < t_end;
+      const int64_t st = ok ? tl - t0 : 0;
       const unsigned keep = ok ? 0xFFFFFFFFu : 0u;  // branch-free zeroing of out-of-range steps
 #pragma unroll
       for (int q = 0; q < PER_WAVE; ++q) {
@@ -366,10 +368,18 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
   const int wi = wave / WO, wo = wave % WO;
 
   const int64_t per = (n_tiles + pb.n_blocks - 1) / pb.n_blocks;
-  const int64_t t0 = (int64_t)split * per;
+  int64_t t0 = (int64_t)split * per;
   const int64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
-  const int64_t steps = t1 > t0 ? t1 - t0 : 0;
-  const int64_t iters = (steps + kWgSpi - 1) / kWgSpi;
+  int64_t steps = t1 > t0 ? t1 - t0 : 0;
+  int64_t iters = (steps + kWgSpi - 1) / kWgSpi;
+  int64_t iter_stride = kWgSpi, t_end = t1;
+  if (lay.interleave) {  // the splits of a problem walk the tiles side by side
+    t0 = (int64_t)split * kWgSpi;
+    iter_stride = (int64_t)pb.n_blocks * kWgSpi;
+    t_end = n_tiles;
+    iters = t0 < n_tiles ? (n_tiles - t0 + iter_stride - 1) / iter_stride : 0;
+    steps = iters * kWgSpi;
+  }
 
   Stage stg;
   stg.x_src = save + lane * 16;
@@ -380,6 +390,8 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
   stg.y_slots = lay.y_slots;
   stg.t0 = t0;
   stg.n_tiles = n_tiles;
+  stg.iter_stride = iter_stride;
+  stg.t_end = t_end;
   stg.steps = steps;
   stg.wave = wave;
   stg.lane = lane;

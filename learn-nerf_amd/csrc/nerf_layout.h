@@ -336,9 +336,10 @@ constexpr int kGradDy = 12;             // dy8, dy7, ..., dy0: 16 slots each, in
 constexpr int kGradSlots = kGradDy + 9 * 16;  // 156
 // NeRFModel dump layout: tile-major unless built with -DLNRF_DUMP_SLOT_MAJOR (A/B; see fused_chain.h dump_off)
 #ifdef LNRF_DUMP_SLOT_MAJOR
-constexpr int kSaveTileSlots = 0, kGradTileSlots = 0;
+constexpr int kSaveTileSlots = 0, kGradTileSlots = 0, kDirSaveTileSlots = 0, kDirGradTileSlots = 0;
 #else
 constexpr int kSaveTileSlots = kSaveSlots, kGradTileSlots = kGradSlots;
+constexpr int kDirSaveTileSlots = kDirSaveSlots, kDirGradTileSlots = kDirGradSlots;  // Ref-NeRF directional block
 #endif
 NL_HD constexpr int grad_dy_slot(int l) { return kGradDy + (8 - l) * 16; }
 

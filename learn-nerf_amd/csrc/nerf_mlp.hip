@@ -710,6 +710,10 @@ int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_wgrad_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+  {
+    static const int il = [] { const char* v = getenv("LNRF_WGRAD_INTERLEAVE"); return v ? atoi(v) : 0; }();
+    lay.interleave = il;
+  }
   hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args, (const char*)xbuf,
                      (const char*)ybuf, n_tiles, grads, lay);
   LNRF_LAUNCH_CHECK();

@@ -36,12 +36,12 @@ __device__ __forceinline__ void load_relu_masks(uint4 (&mask)[8], const char* __
                                                 int64_t tile, int lane) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
-    mask[i] = *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) * kFragBytes + lane * 16);
+    mask[i] = *reinterpret_cast<const uint4*>(save + dump_off(kSaveMask + i, tile, n_tiles, kSaveTileSlots) + lane * 16);
 }
 // ReLU mask of h_i (written by the trunk forward), 16 bytes per lane
 __device__ __forceinline__ uint4 load_relu_mask(int i, const char* __restrict__ save, int64_t n_tiles, int64_t tile,
                                                 int lane) {
-  return *reinterpret_cast<const uint4*>(save + ((int64_t)(kSaveMask + i) * n_tiles + tile) * kFragBytes + lane * 16);
+  return *reinterpret_cast<const uint4*>(save + dump_off(kSaveMask + i, tile, n_tiles, kSaveTileSlots) + lane * 16);
 }
 __device__ __forceinline__ unsigned mask_word(const uint4& mk, int o) {
   return (o >> 1) == 0 ? mk.x : ((o >> 1) == 1 ? mk.y : ((o >> 1) == 2 ? mk.z : mk.w));
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_trunk_fwd_kernel(
       xe[ks][2 * pp + 1] = (__bf16)co;
     }
   });
-  DumpAddr dump{save, n_tiles, tile, c, h};
+  DumpAddr dump{save, n_tiles, tile, c, h, kSaveTileSlots};
   static_for<4>([&](auto i) { stream_store(dump.at(kSaveXin + decltype(i)::value), frag_to_bits(xe[decltype(i)::value])); });
 
   bf16x8 a0[16], a1[16];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_trunk_fwd_kernel(
           stream_store(dump.at(kSaveH + 16 * S + 2 * o + 1), frag_to_bits(out[2 * o + 1]));
           mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
         });
-    *reinterpret_cast<uint4*>(save + ((int64_t)(kSaveMask + S) * n_tiles + tile) * kFragBytes + lane * 16) =
+    *reinterpret_cast<uint4*>(save + dump_off(kSaveMask + S, tile, n_tiles, kSaveTileSlots) + lane * 16) =
         make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
     mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
   };
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_normal_kernel(
   ring.lane = lane;
   ring.prologue();
 
-  DumpAddr gd{cdump, n_tiles, tile, c, h};
+  DumpAddr gd{cdump, n_tiles, tile, c, h, kGradTileSlots};
   bf16x8 a0[16], a1[16];
   // seed c_8 = -e_0: feature 0 is k slot (ks 0, h 0, j 0)
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_trunk_bwd_chain_kernel(
   ring.wave = wave;
   ring.lane = lane;
   ring.prologue();
-  DumpAddr gd{gdump, n_tiles, tile, c, h};
+  DumpAddr gd{gdump, n_tiles, tile, c, h, kGradTileSlots};
 #pragma unroll
   for (int i = 0; i < 16; ++i) stream_store(gd.at(grad_dy_slot(8) + i), frag_to_bits(a1[i]));
   hidden_back<0 * 128, 8>(ring, a1, a0, mask[7], gd);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_tangent_kernel(
   ring.lane = lane;
   ring.prologue();
 
-  DumpAddr td{tdump, n_tiles, tile, c, h};
+  DumpAddr td{tdump, n_tiles, tile, c, h, kSaveTileSlots};
   bf16x8 xe[4];
   static_for<4>([&](auto ks_) {
     constexpr int ks = decltype(ks_)::value;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_dir_fwd_kernel(
   ring.wave = wave;
   ring.lane = lane;
   ring.prologue();
-  DumpAddr dump{dsave, n_tiles, tile, c, h};
+  DumpAddr dump{dsave, n_tiles, tile, c, h, kDirSaveTileSlots};
   static_for<18>([&](auto i) { stream_store(dump.at(kDirSaveXin + decltype(i)::value), frag_to_bits(xin[decltype(i)::value])); });
   bf16x8 hcol[8];
   unsigned mask_bits[2] = {0u, 0u};
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void refnerf_dir_fwd_kernel(
         stream_store(dump.at(kDirSaveH + 2 * o + 1), frag_to_bits(hcol[2 * o + 1]));
         mask_bits[o >> 1] |= relu_bits(hcol[2 * o], hcol[2 * o + 1]) << (16 * (o & 1));
       });
-  *reinterpret_cast<uint4*>(dsave + ((int64_t)kDirSaveMask * n_tiles + tile) * kFragBytes + lane * 16) =
+  *reinterpret_cast<uint4*>(dsave + dump_off(kDirSaveMask, tile, n_tiles, kDirSaveTileSlots) + lane * 16) =
       make_uint4(mask_bits[0], mask_bits[1], 0u, 0u);
   chain_layer<72, 8, 1>(
       ring, [&](auto) { return bias_acc(128, h); }, [&](auto k_) -> bf16x8 { return hcol[decltype(k_)::value]; },
@@ -508,14 +508,14 @@ __global__ __launch_bounds__(kThreads) void refnerf_dir_bwd_kernel(
     dy10[1] = (__bf16)g_do[m * 3 + 1];
     dy10[2] = (__bf16)g_do[m * 3 + 2];
   }
-  const uint4 mk = *reinterpret_cast<const uint4*>(dsave + ((int64_t)kDirSaveMask * n_tiles + tile) * kFragBytes + lane * 16);
+  const uint4 mk = *reinterpret_cast<const uint4*>(dsave + dump_off(kDirSaveMask, tile, n_tiles, kDirSaveTileSlots) + lane * 16);
   __syncthreads();
   Ring<kDirBwdFrags / kStageFrags, DirBwdSeq> ring;
   ring.stream = packed + kRefPackDirBwdOff;
   ring.wave = wave;
   ring.lane = lane;
   ring.prologue();
-  DumpAddr gd{gdump, n_tiles, tile, c, h};
+  DumpAddr gd{gdump, n_tiles, tile, c, h, kDirGradTileSlots};
   stream_store(gd.at(kDirGradDy10), frag_to_bits(dy10));
   stream_store(gd.at(kDirGradDy10 + 1), frag_to_bits(zero_frag()));
   bf16x8 dy9[8];
@@ -682,7 +682,7 @@ static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int 
   for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, do_bias, 56);
   add(2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, do_bias, 32);
   add(2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, 0, 32);
-  return launch_nerf_wgrad(a, first, xbuf, ybuf, n_tiles, grads, st);
+  return launch_nerf_wgrad(a, first, xbuf, ybuf, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots});
 }
 
 extern "C" int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, const float* g_spatial, int64_t ld,
@@ -763,5 +763,6 @@ extern "C" int lnrf_refnerf_dir_bwd(const void* packed, const void* dsave, const
   };
   add(5, kDirSaveXin, kDirGradDy9, kDirHidden, kDirIn, kDirW9, kDirB9, 400);
   add(4, kDirSaveH, kDirGradDy10, 3, kDirHidden, kDirW10, kDirB10, 112);
-  return launch_nerf_wgrad(a, first, dsave, scratch, n_tiles, grads, as_stream(stream));
+  return launch_nerf_wgrad(a, first, dsave, scratch, n_tiles, grads, as_stream(stream),
+                           WgLayout{kDirSaveTileSlots, kDirGradTileSlots});
 }
