@@ -32,7 +32,7 @@ NL_HD constexpr int flag_of_slot(int slot) { return slot < kGradDy ? 0 : 1 + (sl
 NL_HD constexpr int flag_slot0(int f) { return f == 0 ? 0 : kGradDy + 16 * (f - 1); }
 NL_HD constexpr int flag_slots(int f) { return f == 0 ? kGradDy : 16; }
 
-// Sink of the separate-launch path: fragments go to the [slot][tile][1 KiB] gradient dump with non-temporal stores.
+// Sink of the separate-launch path: fragments go to the gradient dump (layout: fused_chain.h dump_off) with non-temporal stores.
 struct GlobalDumpSink {
   DumpAddr gd;
   template <int F>
@@ -211,7 +211,7 @@ struct NerfWgradEpi {
 };
 
 // launches nerf_wgrad_kernel (nerf_mlp.hip) on `blocks` workgroups: X operands from xbuf, dy operands from ybuf (both
-// [slot][tile][1 KiB] dumps with n_tiles tiles per slot)
+// dumps of n_tiles tiles in the layout `lay` names: slot-major by default, see fused_chain.h dump_off)
 int launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
                       float* grads, hipStream_t stream, WgLayout lay = WgLayout{});
 

@@ -300,7 +300,7 @@ NL_HD constexpr int dir_bwd_weight_index(int g, int lane, int j) {
   return -1;
 }
 NL_HD constexpr int dir_bias_index(int i) { return i < 128 ? kDirB9 + i : (i < 131 ? kDirB10 + (i - 128) : -1); }
-// saved by the directional forward ([slot][tile][1 KiB]): the 18 input fragments, relu(Dense_9) (8), its mask (1)
+// saved by the directional forward (1 KiB fragments, layout: fused_chain.h dump_off): the 18 input fragments, relu(Dense_9) (8), its mask (1)
 constexpr int kDirSaveXin = 0, kDirSaveH = 18, kDirSaveMask = 26, kDirSaveSlots = 27;
 // dumped by the directional backward: dy10 (2 slots, second zero) then dy9 (8 slots)
 constexpr int kDirGradDy10 = 0, kDirGradDy9 = 2, kDirGradSlots = 10;
@@ -313,7 +313,8 @@ constexpr int64_t kRefPackDirBiasOff = kRefPackDirBwdOff + (int64_t)kDirBwdFrags
 constexpr int64_t kRefPackBytes = kRefPackDirBiasOff + 1024;
 
 // ---- saved activations / gradient dumps -------------------------------------------------------
-// Both buffers are [slot][tile][1 KiB]; a slot is one k-step (16 features) of one tensor.
+// Both buffers hold 1 KiB fragments addressed by (slot, tile) through dump_off() (tile-major [tile][slot] unless built with
+// -DLNRF_DUMP_SLOT_MAJOR); a slot is one k-step (16 features) of one tensor.
 // Inside the 1 KiB block lane (c, hh) of frag slot F stores its 16 bytes at dump_lane_off():
 // the permutation makes the transposed LDS reads of the weight-gradient kernel conflict-free.
 NL_HD constexpr int dump_lane_off(int slot, int c, int hh) {
