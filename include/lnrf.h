@@ -293,7 +293,9 @@ int64_t lnrf_nerf_param_count(const lnrf_nerf_shape* shape);
 int64_t lnrf_nerf_packed_bytes(const lnrf_nerf_shape* shape);
 /* bytes of the saved-activation buffer for m evaluations (forward -> backward). */
 int64_t lnrf_nerf_save_bytes(const lnrf_nerf_shape* shape, int64_t m);
-/* bytes of backward scratch (pre-activation gradients in fragment order) for m evaluations. */
+/* bytes of backward scratch for m evaluations: the pre-activation gradients in fragment order (written by
+ * lnrf_nerf_mlp_bwd_chain, read by lnrf_nerf_mlp_bwd_weights) followed by the partial-sum slabs that
+ * lnrf_nerf_mlp_bwd_weights writes and folds (deterministic reduction instead of fp32 atomics). */
 int64_t lnrf_nerf_bwd_scratch_bytes(const lnrf_nerf_shape* shape, int64_t m);
 
 /* Repack fp32 Flax-layout parameters into the bf16 fragment streams (forward + transposed). */
@@ -354,8 +356,9 @@ int lnrf_nerf_mlp_bwd_chain(const lnrf_nerf_shape* shape, const void* packed, co
                             const float* density, const float* rgb, const float* g_density,
                             const float* g_rgb, int64_t m, void* scratch, lnrf_stream_t stream);
 
-/* Part 2: grads += X_l^T dy_l for every Dense kernel and sum_m dy_l for every bias. */
-int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
+/* Part 2: grads += X_l^T dy_l for every Dense kernel and sum_m dy_l for every bias.  Reads the gradient dump at
+ * the start of scratch and uses the slab region behind it (lnrf_nerf_bwd_scratch_bytes covers both). */
+int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, void* scratch,
                               int64_t m, float* grads, lnrf_stream_t stream);
 
 /* ---- fused spatial block of RefNERFModel (reference learn_nerf/ref_nerf.py:80-107; csrc/refnerf_fused.hip) ----

@@ -346,12 +346,19 @@ struct WgStage {
   }
 };
 
+// slab epilogue of wgrad_body: floats per (workgroup, wave): up to 8 accumulator tiles of 64 lanes x 16 + 4 bias rows
+constexpr int kSlabMaxTiles = 8, kSlabMaxTO = 4;
+constexpr int kSlabTileFloats = 64 * 16;
+constexpr int kSlabWaveFloats = kSlabMaxTiles * kSlabTileFloats + kSlabMaxTO * 64;
+constexpr int64_t kSlabBlockBytes = (int64_t)kWaves * kSlabWaveFloats * (int64_t)sizeof(float);
+
 // PB supplies x_slot0, y_slot0, do_bias, first_block, n_blocks; EPI maps (out tile, column) and
 // (X fragment, row) to gradient-vector offsets.
 template <int NXF, int NYF, int WI, int WO, int SPI, class EPI, class PB>
 __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict__ save,
                                            const char* __restrict__ gdump, int64_t n_tiles,
-                                           float* __restrict__ grads, WgLayout lay = WgLayout{}) {
+                                           float* __restrict__ grads, WgLayout lay = WgLayout{},
+                                           float* __restrict__ slabs = nullptr) {
   constexpr int NI = NXF / 2, NO = NYF / 2;
   constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;  // tiles per wave
   constexpr bool FULL_I = TI * WI == NI, FULL_O = TO * WO == NO;   // every wave owns TI x TO real tiles
@@ -464,6 +471,29 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
 #ifdef LNRF_NO_FLUSH
   if (n_tiles >= 0) return;  // timing experiment only (results are wrong): what the epilogue below costs
 #endif
+  if (slabs != nullptr) {
+    // Slab epilogue: the workgroup's accumulators leave as they stand — [workgroup][wave][tile a * TO + b][4][lane][4 f32],
+    // 4 KiB per tile written as four 1 KiB store instructions — plus the per-lane bias partial sums of the wi == 0 waves;
+    // wgrad_reduce_tile() folds the slabs of a problem in a fixed order and runs the index mapping below once.  Against
+    // fp32 atomics (memory-side, ~1.3 TB/s of added bytes chip-wide: 62-67 us for the ~100 MB of one NeRFModel launch)
+    // the partial sums move at store / load rates, and the gradient no longer depends on arrival order.
+    float* __restrict__ mine = slabs + ((int64_t)blockIdx.x * kWaves + wave) * kSlabWaveFloats;
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TO; ++b) {
+        // [tile][v][lane][4 f32]: every store instruction writes 1 KiB contiguous
+        float4* dst = reinterpret_cast<float4*>(mine + (a * TO + b) * kSlabTileFloats) + lane;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          dst[64 * v] = make_float4(acc[a][b][4 * v], acc[a][b][4 * v + 1], acc[a][b][4 * v + 2], acc[a][b][4 * v + 3]);
+      }
+    if (wi == 0) {
+#pragma unroll
+      for (int b = 0; b < TO; ++b) mine[kSlabTileFloats * kSlabMaxTiles + b * 64 + lane] = bsum[b];
+    }
+    return;
+  }
   // epilogue: atomically add the partial dW tiles / bias sums
   const int colr = lane & 31, hh = lane >> 5;
   static_for<TO>([&](auto b_) {
@@ -492,6 +522,89 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
       });
     });
   });
+}
+
+// A 4-wave workgroup folds ONE accumulator tile (wave w of the producing workgroups, tile j = a * TO + b) of a problem
+// over the problem's n_blocks slabs: wave q sums the slabs q, q + 4, ... in order, the four partial sums meet in LDS and
+// wave 0 adds them (q = 0..3) and applies the same index mapping as the atomic epilogue of wgrad_body.  The order of
+// every addition is fixed and every parameter has exactly one owner tile (plain read-modify-write): bit-reproducible.
+constexpr int kSlabReduceWaves = 4;
+template <int NXF, int NYF, int WI, int WO, class EPI, class PB>
+__device__ __forceinline__ void wgrad_reduce_tile(const PB& pb, int w, int j, const float* __restrict__ slabs,
+                                                  float* __restrict__ grads, float* lds) {
+  constexpr int NI = NXF / 2, NO = NYF / 2;
+  constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;
+  static_assert(TI * TO <= kSlabMaxTiles && TO <= kSlabMaxTO, "slab layout");
+  if (j >= TI * TO) return;  // uniform for the workgroup
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int a = j / TO, b = j % TO;
+  const int wi = w / WO, wo = w % WO;
+  const int it = wi + WI * a, ot = wo + WO * b;
+  if (it >= NI || ot >= NO) return;
+  const float* __restrict__ src = slabs + ((int64_t)pb.first_block * kWaves + w) * kSlabWaveFloats;
+  const int64_t blk_stride = (int64_t)kWaves * kSlabWaveFloats;
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const bool bias = wi == 0 && a == 0 && pb.do_bias;
+  float bsum = 0.0f;
+  constexpr int U = 4;  // slabs in flight per wave
+  for (int s0 = q; s0 < pb.n_blocks; s0 += U * kSlabReduceWaves) {
+    float4 t[U][4];
+    float bb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sb = s0 + u * kSlabReduceWaves;
+      const int sblk = sb < pb.n_blocks ? sb : pb.n_blocks - 1;
+      const float* base = src + (int64_t)sblk * blk_stride;
+      const float4* tp = reinterpret_cast<const float4*>(base + j * kSlabTileFloats) + lane;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[u][v] = tp[64 * v];
+      bb[u] = bias ? base[kSlabTileFloats * kSlabMaxTiles + b * 64 + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = s0 + u * kSlabReduceWaves < pb.n_blocks;  // the tail re-reads the last slab and adds zeros
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        acc[4 * v] += ok ? t[u][v].x : 0.0f;
+        acc[4 * v + 1] += ok ? t[u][v].y : 0.0f;
+        acc[4 * v + 2] += ok ? t[u][v].z : 0.0f;
+        acc[4 * v + 3] += ok ? t[u][v].w : 0.0f;
+      }
+      bsum += ok ? bb[u] : 0.0f;
+    }
+  }
+  // partial sums of waves 1..3 -> LDS [q][17][64]
+  if (q > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[((q - 1) * 17 + r) * 64 + lane] = acc[r];
+    lds[((q - 1) * 17 + 16) * 64 + lane] = bsum;
+  }
+  __syncthreads();
+  if (q > 0) return;
+#pragma unroll
+  for (int p = 0; p < kSlabReduceWaves - 1; ++p) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += lds[(p * 17 + r) * 64 + lane];
+    bsum += lds[(p * 17 + 16) * 64 + lane];
+  }
+  const int colr = lane & 31, hh = lane >> 5;
+  int out_idx = -1, out_dim = 1;
+  int64_t w_off = 0, b_off = 0;
+  EPI::cols(pb, ot, colr, out_idx, out_dim, w_off, b_off);
+  if (bias) {
+    float sacc = bsum;
+    sacc += __shfl_xor(sacc, 32, 64);
+    if (hh == 0 && out_idx >= 0) grads[b_off + out_idx] += sacc;
+  }
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) {
+    const int r = (qq & 3) + 8 * (qq >> 2) + 4 * hh;  // row in the 32-feature tile
+    const int f = 2 * it + (r >> 4);                   // k-step slot within X
+    const int in_idx = EPI::row(pb, f, r & 15);
+    if (out_idx >= 0 && in_idx >= 0) grads[w_off + (int64_t)in_idx * out_dim + out_idx] += acc[qq];
+  }
 }
 
 }  // namespace lnrf

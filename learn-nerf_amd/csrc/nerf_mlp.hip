@@ -453,19 +453,36 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
 __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, const char* __restrict__ save,
                                                               const char* __restrict__ gdump,
                                                               int64_t n_tiles, float* __restrict__ grads,
-                                                              WgLayout lay) {
+                                                              WgLayout lay, float* __restrict__ slabs) {
   WgradProblem pb = args.p[0];
 #pragma unroll
   for (int i = 1; i < kMaxProblems; ++i)
     if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
   switch (pb.shape) {
     // steps per barrier chosen so that every body keeps ~60 KB of loads in flight per workgroup
-    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
-    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
-    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
-    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
-    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;  // Ref-NeRF Dense_9
-    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay); break;
+    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // Ref-NeRF Dense_9
+    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+  }
+}
+
+// Folds the slabs of a nerf_wgrad_kernel launch (slab epilogue): blockIdx.x = problem * 64 + wave * 8 + tile.
+__global__ __launch_bounds__(64 * kSlabReduceWaves) void nerf_wgrad_reduce_kernel(WgradArgs args,
+                                                                                 const float* __restrict__ slabs,
+                                                                                 float* __restrict__ grads) {
+  __shared__ float lds[(kSlabReduceWaves - 1) * 17 * 64];
+  const int prob = blockIdx.x >> 6, w = (blockIdx.x >> 3) & 7, j = blockIdx.x & 7;
+  const WgradProblem pb = args.p[prob];
+  switch (pb.shape) {  // the shapes of nerf_wgrad_kernel
+    case 0: wgrad_reduce_tile<16, 16, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    case 1: wgrad_reduce_tile<16, 10, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    case 2: wgrad_reduce_tile<4, 16, 2, 4, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    case 3: wgrad_reduce_tile<2, 10, 1, 8, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    case 5: wgrad_reduce_tile<18, 8, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    default: wgrad_reduce_tile<8, 2, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
   }
 }
 
@@ -566,8 +583,12 @@ extern "C" int64_t lnrf_nerf_packed_bytes(const lnrf_nerf_shape* s) {
 extern "C" int64_t lnrf_nerf_save_bytes(const lnrf_nerf_shape* s, int64_t m) {
   return shape_supported(s) ? (int64_t)kSaveSlots * tiles_for(m) * kFragBytes : -1;
 }
+// weight-gradient workgroups of one NeRFModel launch (sum of the per-problem counts in lnrf_nerf_mlp_bwd_weights)
+constexpr int kNerfWgradBlocks = 512;
+static int64_t grad_dump_bytes(int64_t m) { return (int64_t)kGradSlots * tiles_for(m) * kFragBytes; }
 extern "C" int64_t lnrf_nerf_bwd_scratch_bytes(const lnrf_nerf_shape* s, int64_t m) {
-  return shape_supported(s) ? (int64_t)kGradSlots * tiles_for(m) * kFragBytes : -1;
+  // the dy dump, then the partial-sum slabs of the weight-gradient launch (fused_chain.h, slab epilogue)
+  return shape_supported(s) ? grad_dump_bytes(m) + kNerfWgradBlocks * kSlabBlockBytes : -1;
 }
 
 extern "C" int lnrf_nerf_pack_weights(const lnrf_nerf_shape* shape, const float* params, void* packed,
@@ -705,7 +726,7 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
 }
 
 int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
-                            float* grads, hipStream_t stream, WgLayout lay) {
+                            float* grads, hipStream_t stream, WgLayout lay, float* slabs) {
   const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_wgrad_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -715,12 +736,17 @@ int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf,
     lay.interleave = il;
   }
   hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args, (const char*)xbuf,
-                     (const char*)ybuf, n_tiles, grads, lay);
+                     (const char*)ybuf, n_tiles, grads, lay, slabs);
   LNRF_LAUNCH_CHECK();
+  if (slabs != nullptr) {  // room for `blocks` slabs of kSlabBlockBytes is the caller's business
+    hipLaunchKernelGGL(nerf_wgrad_reduce_kernel, dim3((unsigned)(args.n_problems * 64)), dim3(64 * kSlabReduceWaves), 0, stream, args,
+                       (const float*)slabs, grads);
+    LNRF_LAUNCH_CHECK();
+  }
   return LNRF_OK;
 }
 
-extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, const void* scratch,
+extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, void* scratch,
                                          int64_t m, float* grads, lnrf_stream_t stream) {
   if (!shape_supported(shape)) {
     set_error("lnrf_nerf_mlp_bwd_weights: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
@@ -743,7 +769,12 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   }
   const int first = build_wgrad_problems(a, blocks, (n_tiles + 5) / 6);
   (void)rc;
-  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots});
+  // LNRF_WGRAD_ATOMICS=1 keeps the older fp32-atomic epilogue (A/B)
+  static const bool atomics = [] { const char* v = getenv("LNRF_WGRAD_ATOMICS"); return v && v[0] == '1'; }();
+  float* slabs = (atomics || first > kNerfWgradBlocks)
+                     ? nullptr
+                     : reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + grad_dump_bytes(m));
+  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots}, slabs);
 }
 
 #ifdef LNRF_TIMELINE

@@ -223,6 +223,26 @@ def test_fused_bf16_backward(m):
 
 
 @pytest.mark.parametrize("m", [32, 8192 + 17, 70000])
+def test_backward_is_bit_reproducible(m):
+    """The weight-gradient launch leaves its partial sums as slabs that a second launch folds in a fixed order
+    (fused_chain.h, slab epilogue), so two backward passes over the same inputs give bit-identical gradients — which
+    fp32 atomics (LNRF_WGRAD_ATOMICS=1, the older epilogue) do not.  Kernel and bias gradients, ragged and multi-workgroup
+    sizes."""
+    model, _, flat = make_model("bf16")
+    x, d, gen = make_points(m, seed=3)
+    g_dens = torch.randn(m, generator=gen).float().cuda()
+    g_rgb = torch.randn(m, 3, generator=gen).float().cuda()
+    grads = []
+    for _ in range(3):
+        dens, rgb, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+        g = torch.zeros_like(flat)
+        model.backward(ctx, g_dens, g_rgb, None, g)
+        grads.append(g)
+    assert grads[0].abs().max().item() > 0
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+@pytest.mark.parametrize("m", [32, 8192 + 17, 70000])
 def test_persistent_fused_backward_equals_two_launch_backward(m):
     """lnrf_nerf_mlp_bwd_fused (one persistent launch: chain workgroups hand dy to weight-gradient workgroups through
     ring buffers) must give the gradients of lnrf_nerf_mlp_bwd_chain + _bwd_weights: same bf16 operands, same fp32
