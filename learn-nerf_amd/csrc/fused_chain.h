@@ -374,7 +374,8 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WO, wo = wave % WO;
 
-  const int64_t per = (n_tiles + pb.n_blocks - 1) / pb.n_blocks;
+  int64_t per = (n_tiles + pb.n_blocks - 1) / pb.n_blocks;
+  per = (per + kDumpGroup - 1) / kDumpGroup * kDumpGroup;  // K-slices start on a tile group of the dump layout
   int64_t t0 = (int64_t)split * per;
   const int64_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
   int64_t steps = t1 > t0 ? t1 - t0 : 0;
