@@ -139,22 +139,46 @@ def use_abi_comm(comm: Optional[AbiComm]) -> None:
     _abi_comm = comm
 
 
-def reduce_gradient_(flat: torch.Tensor) -> float:
+def reduce_gradient_(flat: torch.Tensor, reduced_prefix: int = 0, pending=None) -> float:
     """
+    reduced_prefix / pending: the first `reduced_prefix` floats are already being reduced by begin_reduce_ (handle
+    `pending`): only the rest is exchanged here, then the handle is waited for.
+
     The ONE exchange of a data-parallel step: in-place all-reduce (sum) of the flat gradient — over the C-ABI
     RCCL communicator when use_abi_comm() installed one, else over the default torch.distributed process group
     (RCCL on GPUs, gloo on CPU tensors), issued whenever a group exists, also with a single rank, so the collective
     path is exercised by every torchrun launch.  Returns the factor 1/world that the caller folds into Adam
     (grad_scale) and into the logged grad_norm.
     """
+    if pending is None:
+        reduced_prefix = 0
+    rest = flat[reduced_prefix:] if reduced_prefix else flat
     if _abi_comm is not None:
-        _abi_comm.all_reduce_sum_(flat)
+        _abi_comm.all_reduce_sum_(rest)
         return 1.0 / _abi_comm.world
     d = dist_module()
     if d is None:
         return 1.0
-    d.all_reduce(flat)
+    d.all_reduce(rest)
+    if pending is not None:
+        pending.wait()  # the compute stream waits for the early slice (gloo: the host does)
     return 1.0 / d.get_world_size()
+
+
+def begin_reduce_(part: torch.Tensor):
+    """
+    Start the all-reduce (sum) of a finished slice of the gradient while the rest of the backward still runs: with
+    torch.distributed the collective is issued asynchronously (RCCL's own stream, ordered after what the current stream
+    has enqueued so far) and the returned handle is waited for right before the optimizer (reduce_gradient_(...,
+    pending=handle)).  Returns None when there is nothing to overlap — no process group, or the C-ABI communicator,
+    whose collective is stream-ordered on the compute stream: the caller then reduces the whole buffer at the end.
+    """
+    if _abi_comm is not None:
+        return None
+    d = dist_module()
+    if d is None:
+        return None
+    return d.all_reduce(part, async_op=True)
 
 
 def grad_scale() -> float:

@@ -102,6 +102,7 @@ class TrainLoop:
         want = (env != "0") if env is not None else bool(getattr(coarse, "overlap_backward_hint", True))
         self.overlap_backward = torch.device(self.device).type == "cuda" and coarse is not fine and want
         self._side_stream = None
+        self._early_reduce = (0, None)  # (floats already handed to the all-reduce, its handle) of the running step
 
     def _params_changed(self):
         # the kernels write through raw pointers, which torch's version counters do not see
@@ -231,6 +232,9 @@ class TrainLoop:
         if want_grad:
             if coarse_done is None:
                 backward_of(*coarse_args)
+                if self.density_penalty is None:
+                    # the coarse model's gradient is final: its all-reduce runs under the fine backward (data parallel)
+                    self._early_reduce = (self.n_coarse, parallel.begin_reduce_(gc))
             backward_of(ts_f, dens_f, rgb_f, out_f, self.fine, ctx_f, gf, names_f, auxs_f)
             if coarse_done is not None:
                 torch.cuda.current_stream(self.device).wait_event(coarse_done)  # join before anything reads the gradient
@@ -264,11 +268,14 @@ class TrainLoop:
 
     def _step(self, key, bmin, bmax, batch):
         self.grad.zero_()
+        self._early_reduce = (0, None)
         aux_losses, _ = self._forward_backward(key, bmin, bmax, batch.contiguous(), self.flat, self.grad, True)
         self.state.step += 1
         sc = self._scalars
+        prefix, pending = self._early_reduce
         scale = apply_gradients(self.flat, self.grad, self.state.opt_m, self.state.opt_v, self.state.step, self.lr,
-                                self.adam_b1, self.adam_b2, self.adam_eps, sq_norms=sc[2:4])
+                                self.adam_b1, self.adam_b2, self.adam_eps, sq_norms=sc[2:4],
+                                reduced_prefix=prefix, pending=pending)
         log = ops.step_log(sc, 1.0 / (3.0 * batch.shape[0]), scale, clear=True)  # one launch; zeroes sc again
         self._scalars_dirty = False
         self._params_changed()
@@ -307,10 +314,12 @@ class TrainLoop:
 
 
 def apply_gradients(flat, grad, opt_m, opt_v, step: int, lr: float, b1: float, b2: float, eps: float,
-                    sq_norms: torch.Tensor, kernels=ops) -> float:
+                    sq_norms: torch.Tensor, kernels=ops, reduced_prefix: int = 0, pending=None) -> float:
     """
     What follows jax.grad in the reference's step (train.py:99-106), in its data-parallel form:
-      1. ONE all-reduce (sum) of the flat gradient over the process group (parallel.reduce_gradient_),
+      1. the all-reduce (sum) of the flat gradient over the process group (parallel.reduce_gradient_): one collective,
+         or two when the caller has already started the coarse model's slice with parallel.begin_reduce_ while the fine
+         backward was running (`reduced_prefix` floats, handle `pending`) — the same sums either way,
       2. optax.adam as at train.py:59 with the mean over ranks folded in as grad_scale = 1/world, and in the same
          pass over the buffers
       3. the tree_norm numerators (train.py:92-104) of the REDUCED gradient and of the parameters before the update:
@@ -320,7 +329,7 @@ def apply_gradients(flat, grad, opt_m, opt_v, step: int, lr: float, b1: float, b
     (HIP) in the product; tests/test_dp_gloo.py passes a CPU implementation to drive this same sequence under gloo.
     """
     with _prof.section("allreduce"):
-        scale = parallel.reduce_gradient_(grad)
+        scale = parallel.reduce_gradient_(grad, reduced_prefix, pending)
     with _prof.section("norms_adam"):
         kernels.adam_step_(flat, grad, opt_m, opt_v, lr, b1, b2, eps, step, grad_scale=scale, sq_norms=sq_norms)
     return scale

@@ -132,7 +132,14 @@ def _update_worker(rank, world, port, out_dir):
     for step in (1, 2):  # two steps: the second one sees non-zero moments
         g = grad.clone() * (1.0 if step == 1 else 0.5)
         sq = torch.zeros(2, dtype=torch.float64)
-        scale = apply_gradients(flat, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7, sq_norms=sq, kernels=CpuKernels)
+        if step == 1:  # one collective over the whole buffer
+            scale = apply_gradients(flat, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7, sq_norms=sq, kernels=CpuKernels)
+        else:  # the product's overlapped form: the coarse slice starts early, the rest follows, same sums
+            n_early = cf.numel()
+            pending = parallel.begin_reduce_(g[:n_early])
+            assert pending is not None
+            scale = apply_gradients(flat, g, m, v, step, 1e-3, 0.9, 0.999, 1e-7, sq_norms=sq, kernels=CpuKernels,
+                                    reduced_prefix=n_early, pending=pending)
         assert scale == 1.0 / world
         logs.append(dict(grad_norm=float(sq[0].sqrt()) * scale, param_norm=float(sq[1].sqrt())))
     torch.save(dict(flat=flat, m=m, v=v, logs=logs), os.path.join(out_dir, f"u{rank}.pt"))
