@@ -281,6 +281,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short ngp / refnerf legs")
+    ap.add_argument("--comm-abi-check", action="store_true",
+                    help="N > 1: after every measurement, also reduce a probe vector through the C-ABI RCCL entries "
+                         "(lnrf_comm_*) across the ranks and report it as comm_abi_check (opt-in: a second RCCL "
+                         "communicator next to torch.distributed's has only been exercised with one rank so far)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -466,7 +470,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "nerf":
             out["cpu_baseline"] = cpu_baseline()
     clean = True
-    if world > 1:  # last: nothing measured above can be disturbed by it (rank 0 arrives here after its extra timings)
+    if world > 1 and args.comm_abi_check:  # last: nothing measured above can be disturbed by it
         msg, clean = comm_abi_probe(dist, rank, world, local_rank, device)
         if rank == 0:
             out["comm_abi_check"] = msg
