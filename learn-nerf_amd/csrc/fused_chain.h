@@ -203,7 +203,11 @@ __device__ __forceinline__ bf16x8 masked_frag(const f32x16& acc, unsigned bits, 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stream_store(char* p, uint4 v) {
   u32x4 t = {v.x, v.y, v.z, v.w};
+#ifdef LNRF_PLAIN_DUMP_STORES  // A/B: ordinary write-back stores
+  *reinterpret_cast<u32x4*>(p) = t;
+#else
   __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#endif
 }
 
 // Byte offset of fragment (slot, tile) in a dump buffer.  n_slots == 0: slot-major [slot][tile][1 KiB] (a slot's tiles
@@ -294,7 +298,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* frag_even, int lane, int p
 // global -> VGPR -> LDS staging of one iteration = SPI consecutive 32-evaluation steps
 // (NXF + NYF fragments each, 8 waves).  The registers hold the iteration that is written to LDS
 // after the next barrier; its loads were issued one whole iteration earlier.
-template <int NXF, int NYF, int SPI>  // SPI = steps per iteration (per barrier)
+template <int NXF, int NYF, int SPI, bool PLAIN = false>  // SPI = steps per iteration (per barrier); PLAIN: ordinary loads
 struct WgStage {
   static constexpr int kWgSpi = SPI;
   static constexpr int NF = NXF + NYF;
@@ -326,8 +330,12 @@ struct WgStage {
         if constexpr (NF % kWaves != 0) f = f < NF ? f : NF - 1;
         const char* src = f < NXF ? x_src + dump_off(x_slot0 + f, t0 + st, n_tiles, x_slots)
                                   : y_src + dump_off(y_slot0 + f - NXF, t0 + st, n_tiles, y_slots);
-        // read-once operands: non-temporal loads leave L2 / Infinity Cache to data that is reused
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+        // Non-temporal loads leave L2 / Infinity Cache to data that is reused — measured better for the coarse pass
+        // (1.4 GB of operands: 0.58-0.60 vs 0.61 ms); ordinary loads are better for the fine pass (8.8 GB: 1.53 vs
+        // 1.57-1.58 ms), so the launch picks by size.
+        u32x4 v;
+        if constexpr (PLAIN) v = *reinterpret_cast<const u32x4*>(src);
+        else v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
         rr[u][q] = make_uint4(v[0] & keep, v[1] & keep, v[2] & keep, v[3] & keep);
       }
     }
@@ -354,7 +362,7 @@ constexpr int64_t kSlabBlockBytes = (int64_t)kWaves * kSlabWaveFloats * (int64_t
 
 // PB supplies x_slot0, y_slot0, do_bias, first_block, n_blocks; EPI maps (out tile, column) and
 // (X fragment, row) to gradient-vector offsets.
-template <int NXF, int NYF, int WI, int WO, int SPI, class EPI, class PB>
+template <int NXF, int NYF, int WI, int WO, int SPI, class EPI, bool PLAIN = false, class PB>
 __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict__ save,
                                            const char* __restrict__ gdump, int64_t n_tiles,
                                            float* __restrict__ grads, WgLayout lay = WgLayout{},
@@ -362,7 +370,7 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
   constexpr int NI = NXF / 2, NO = NYF / 2;
   constexpr int TI = (NI + WI - 1) / WI, TO = (NO + WO - 1) / WO;  // tiles per wave
   constexpr bool FULL_I = TI * WI == NI, FULL_O = TO * WO == NO;   // every wave owns TI x TO real tiles
-  using Stage = WgStage<NXF, NYF, SPI>;
+  using Stage = WgStage<NXF, NYF, SPI, PLAIN>;
   constexpr int kWgSpi = SPI;
   static_assert(WI * WO == kWaves, "wave grid");
   static_assert(NXF % 2 == 0 && NYF % 2 == 0, "fragment pairs");

@@ -213,7 +213,8 @@ struct NerfWgradEpi {
 // launches nerf_wgrad_kernel (nerf_mlp.hip) on `blocks` workgroups: X operands from xbuf, dy operands from ybuf (both
 // dumps of n_tiles tiles in the layout `lay` names: slot-major by default, see fused_chain.h dump_off)
 int launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
-                      float* grads, hipStream_t stream, WgLayout lay = WgLayout{}, float* slabs = nullptr);
+                      float* grads, hipStream_t stream, WgLayout lay = WgLayout{}, float* slabs = nullptr,
+                      bool plain_loads = false);
 
 // The 13 problems of one NeRFModel, heaviest first; `blocks[i]` workgroups for problem i (capped by `cap`).
 // Block budget per problem in the order: Dense_1..8 (hidden x hidden), z x dy10m, x_emb x dy0, x_emb x dy5,

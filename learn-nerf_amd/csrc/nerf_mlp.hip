@@ -450,6 +450,7 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_chain_kernel(
 // ---------------------------------------------------------------------------------------------
 // One launch for every Dense layer of the model: blockIdx -> problem -> operand-shape body.
 // Problems are listed heaviest first so that the small ones fill the tail of the launch.
+template <bool PLAIN>
 __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, const char* __restrict__ save,
                                                               const char* __restrict__ gdump,
                                                               int64_t n_tiles, float* __restrict__ grads,
@@ -460,12 +461,12 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
     if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
   switch (pb.shape) {
     // steps per barrier chosen so that every body keeps ~60 KB of loads in flight per workgroup
-    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // Ref-NeRF Dense_9
-    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // Ref-NeRF Dense_9
+    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
   }
 }
 
@@ -726,17 +727,22 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
 }
 
 int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
-                            float* grads, hipStream_t stream, WgLayout lay, float* slabs) {
+                            float* grads, hipStream_t stream, WgLayout lay, float* slabs, bool plain) {
   const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_wgrad_kernel),
+  hipError_t e = hipFuncSetAttribute(plain ? reinterpret_cast<const void*>(nerf_wgrad_kernel<true>)
+                                           : reinterpret_cast<const void*>(nerf_wgrad_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
   {
     static const int il = [] { const char* v = getenv("LNRF_WGRAD_INTERLEAVE"); return v ? atoi(v) : 0; }();
     lay.interleave = il;
   }
-  hipLaunchKernelGGL(nerf_wgrad_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args, (const char*)xbuf,
-                     (const char*)ybuf, n_tiles, grads, lay, slabs);
+  if (plain)
+    hipLaunchKernelGGL(nerf_wgrad_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args,
+                       (const char*)xbuf, (const char*)ybuf, n_tiles, grads, lay, slabs);
+  else
+    hipLaunchKernelGGL(nerf_wgrad_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args,
+                       (const char*)xbuf, (const char*)ybuf, n_tiles, grads, lay, slabs);
   LNRF_LAUNCH_CHECK();
   if (slabs != nullptr) {  // room for `blocks` slabs of kSlabBlockBytes is the caller's business
     hipLaunchKernelGGL(nerf_wgrad_reduce_kernel, dim3((unsigned)(args.n_problems * 64)), dim3(64 * kSlabReduceWaves), 0, stream, args,
@@ -774,7 +780,12 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   float* slabs = (atomics || first > kNerfWgradBlocks)
                      ? nullptr
                      : reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + grad_dump_bytes(m));
-  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots}, slabs);
+  // operand loads (fused_chain.h WgStage::load): ordinary for the big (fine-pass) launch, non-temporal for the small one —
+  // measured on this model only (the Ref-NeRF launches are faster with non-temporal loads at every size);
+  // LNRF_WGRAD_PLAIN_TILES overrides the threshold (tiles of 32 evaluations)
+  static const int64_t plain_from = [] { const char* v = getenv("LNRF_WGRAD_PLAIN_TILES"); return v ? atoll(v) : 16384ll; }();
+  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots}, slabs,
+                           n_tiles >= plain_from);
 }
 
 #ifdef LNRF_TIMELINE
