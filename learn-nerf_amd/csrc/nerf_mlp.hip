@@ -461,12 +461,12 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
     if (i < args.n_problems && (int)blockIdx.x >= args.p[i].first_block) pb = args.p[i];
   switch (pb.shape) {
     // steps per barrier chosen so that every body keeps ~60 KB of loads in flight per workgroup
-    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
-    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // Ref-NeRF Dense_9
-    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi, PLAIN>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 0: wgrad_body<16, 16, 4, 2, 2, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 1: wgrad_body<16, 10, 4, 2, 2, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
+    case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // Ref-NeRF Dense_9
+    default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
   }
 }
 
