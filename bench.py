@@ -17,7 +17,8 @@ all-reduced (sum) over RCCL and averaged inside the fused Adam kernel.
 
 Rank 0 prints ONE JSON line (see the task contract) with these extra objects:
   roofline     — SURVEY.md 8(d): configs[1] is MFMA-bound, so the dominant kernel family's algorithmic FLOP per
-                 launch / its mean HIP-event time in the timed region vs the dense bf16 MFMA peak of MI355X
+                 launch / its mean HIP-event time in the timed region (the weight-gradient family = nerf_wgrad_kernel +
+                 its ~0.03 ms slab-reduce launch) vs the dense bf16 MFMA peak of MI355X
                  (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from the
                  rocprofv3 PMC summary named in `traffic_source` (a separate profiling run, not this one)
   roofline_hbm — the same kernel against the HBM roof (its design bytes per launch / time / 8 TB/s)
