@@ -234,6 +234,20 @@ struct DumpAddr {
   __device__ __forceinline__ char* at(int slot) const {
     return base + dump_off(slot, tile, n_tiles, n_slots) + dump_lane_off(slot, c, hh);
   }
+  // one fragment of this tile, non-temporal.  LNRF_BUFFER_DUMP_STORES (experiment): tile-major buffers take a buffer
+  // store — the tile's block as scalar base, the slot as scalar offset, the lane's 16 bytes as the only vector operand
+  __device__ __forceinline__ void store(int slot, uint4 v) const {
+#ifdef LNRF_BUFFER_DUMP_STORES
+    if (n_slots > 0 && kDumpGroup == 1) {
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(base + tile * n_slots * kFragBytes, 0, 0x7FFFFFFF, 0x00020000);
+      const u32x4 t = {v.x, v.y, v.z, v.w};
+      __builtin_amdgcn_raw_buffer_store_b128(t, rs, dump_lane_off(slot, c, hh), slot * kFragBytes, 2);  // 2 = nt
+      return;
+    }
+#endif
+    stream_store(at(slot), v);
+  }
 };
 // which layout the operand buffers of a weight-gradient launch have (slots per tile, 0 = slot-major)
 struct WgLayout {

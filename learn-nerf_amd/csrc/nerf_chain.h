@@ -39,7 +39,7 @@ struct GlobalDumpSink {
   __device__ __forceinline__ void begin_flag() {}
   template <int F>
   __device__ __forceinline__ void end_flag() {}
-  __device__ __forceinline__ void store(int slot, const bf16x8& f) { stream_store(gd.at(slot), frag_to_bits(f)); }
+  __device__ __forceinline__ void store(int slot, const bf16x8& f) { gd.store(slot, frag_to_bits(f)); }
 };
 
 // Input-gradient chain of the tile owned by this wave (what jax.grad does through model.py:49-60 back to front).

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 
   DumpAddr dump{save, n_tiles, tile, c, h, kSaveTileSlots};
   auto save_frag = [&](int slot, const bf16x8& f) {
-    if (SAVE) stream_store(dump.at(slot), frag_to_bits(f));
+    if (SAVE) dump.store(slot, frag_to_bits(f));
   };
   if (SAVE) {
     static_for<4>([&](auto i) { save_frag(kSaveXin + decltype(i)::value, xe[decltype(i)::value]); });
