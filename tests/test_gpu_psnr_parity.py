@@ -119,8 +119,9 @@ def test_bf16_training_matches_fp32_psnr():
         assert fp32 > 26.0, "the scene must actually be learnt for the comparison to mean anything"
         assert abs(bf16 - fp32) < 0.75, "a single run this far off is not noise"
         deltas.append(bf16 - fp32)
-        if init_seed == SEEDS[0]:
-            # noise floor of the comparison itself: the same fp32 arithmetic with other stratified-sampling noise
+        if init_seed == SEEDS[0] and os.environ.get("LNRF_PSNR_NOISE_FLOOR") == "1":
+            # noise floor of the comparison itself (optional, +30 s): the same fp32 arithmetic with other
+            # stratified-sampling noise; measured -0.03 ... -0.15 dB between runs
             fp32_b, _ = train("fp32", train_rays, test_views, key_offset=100_000, init_seed=init_seed)
             print(f"  fp32 with other sampling noise {fp32_b:.3f} dB (noise floor {fp32_b - fp32:+.3f} dB)")
     n = len(deltas)
