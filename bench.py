@@ -231,8 +231,10 @@ def refnerf_roofline(fams, n, ms_step):
     return roofline, step
 
 
-def short_leg(workload, n, device, table_log2, steps=10, warmup=3):
-    """A few steps of another BASELINE config on this GPU (N = 1 only), so that the driver's record covers it."""
+def short_leg(workload, n, device, table_log2, steps=50, warmup=10):
+    """Another BASELINE config on this GPU (N = 1 only), so that the driver's record covers it.  Every step is timed on
+    its own (host clock around a synchronised step) so that a one-off stall shows up as `max` / `max_at` instead of
+    hiding in a mean: the headline `ms_per_step` is the back-to-back loop, `step_ms` the per-step distribution."""
     from learn_nerf import _prof
     from learn_nerf.rng import Key
 
@@ -242,17 +244,26 @@ def short_leg(workload, n, device, table_log2, steps=10, warmup=3):
     for i in range(warmup):
         step(Key(i), batch)
     torch.cuda.synchronize()
+    per_step = []
+    for i in range(steps):  # pass 1: one synchronised step at a time
+        t1 = time.perf_counter()
+        step(Key(warmup + i), batch)
+        torch.cuda.synchronize()
+        per_step.append(1e3 * (time.perf_counter() - t1))
     _prof.enable(True)
     t0 = time.perf_counter()
-    for i in range(steps):
-        step(Key(warmup + i), batch)
+    for i in range(steps):  # pass 2: back to back (what the headline workload measures)
+        step(Key(warmup + steps + i), batch)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     prof = _prof.summary()
     _prof.enable(False)
+    srt = sorted(per_step)
+    step_ms = dict(median=round(srt[len(srt) // 2], 3), min=round(srt[0], 3), max=round(srt[-1], 3),
+                   max_at=int(per_step.index(srt[-1])), note="synchronised single steps (host clock), before the timed loop")
     fams = {k: dict(ms=round(v[1], 4), calls_per_step=v[0] / steps) for k, v in prof.items()}
     out = dict(ms_per_step=round(ms, 3), value=round(n * (COARSE + FINE) / (ms * 1e-3), 1), unit="ray-samples/s",
-               steps=steps, warmup=warmup)
+               steps=steps, warmup=warmup, step_ms=step_ms)
     if workload == "ngp":
         # whole step against the HBM roof: 663,552 algorithmic bytes per ray
         out["step_hbm"] = dict(achieved=round(n * 663_552 / (ms * 1e-3) / 1e9, 1), peak=8000.0, unit="GB/s",

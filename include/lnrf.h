@@ -332,24 +332,6 @@ int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packed, const vo
                       const float* g_rgb, int64_t m, void* scratch, float* grads,
                       lnrf_stream_t stream);
 
-/* The same backward as ONE persistent launch (csrc/nerf_bwd_fused.hip): chain workgroups and weight-gradient
- * workgroups run side by side, one per CU, and the pre-activation gradients are handed over layer by layer through
- * ring buffers in `workspace` that stay in the Infinity Cache instead of going through HBM.  grads += d L / d params.
- * workspace: lnrf_nerf_bwd_fused_workspace_bytes(shape) bytes, reusable by every call on the same stream; its first
- * int32 is a status word: non-zero after the launch has completed means a bounded hand-off wait gave up (the
- * gradients of that call are then invalid).  Returns LNRF_ERR_UNSUPPORTED when the device cannot keep one workgroup
- * per CU resident — call lnrf_nerf_mlp_bwd then.  lnrf_nerf_bwd_fused_tune: share of producer (chain) workgroups in
- * permille (default 550) and ring buffers per layer (default 64, at most 128). */
-int64_t lnrf_nerf_bwd_fused_workspace_bytes(const lnrf_nerf_shape* shape);
-int lnrf_nerf_mlp_bwd_fused(const lnrf_nerf_shape* shape, const void* packed, const void* save,
-                            const float* density, const float* rgb, const float* g_density,
-                            const float* g_rgb, int64_t m, void* workspace, float* grads,
-                            lnrf_stream_t stream);
-int lnrf_nerf_bwd_fused_tune(int32_t producer_permille, int32_t ring_buffers);
-/* diagnostics only (results are garbage): bit 0 consumers do not wait for producers, bit 1 producers idle,
- * bit 2 producers do not wait for free ring buffers.  0 = normal operation. */
-int lnrf_nerf_bwd_fused_debug(int32_t mode);
-
 /* Part 1: input-gradient chain (what jax.grad does through model.py:49-60 back to front);
  * writes the pre-activation gradients of every Dense layer into scratch (fragment order). */
 int lnrf_nerf_mlp_bwd_chain(const lnrf_nerf_shape* shape, const void* packed, const void* save,

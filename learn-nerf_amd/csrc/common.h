@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/lnrf.h"
 
@@ -31,6 +32,22 @@ inline int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 static inline hipStream_t as_stream(lnrf_stream_t s) { return (hipStream_t)s; }
+
+// A/B switches of past experiments exist in debug builds only (-DLNRF_EXPERIMENTS,
+// tools/build_experiments.sh): the product library reads no environment variable and always takes the default.
+#ifdef LNRF_EXPERIMENTS
+inline int exp_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+inline bool exp_env_is(const char* name, char first) {
+  const char* v = getenv(name);
+  return v && v[0] == first;
+}
+#else
+inline int exp_env_int(const char*, int dflt) { return dflt; }
+inline bool exp_env_is(const char*, char) { return false; }
+#endif
 
 constexpr int kWave = 64;
 

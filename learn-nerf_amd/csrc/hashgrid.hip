@@ -603,21 +603,14 @@ static int check_desc(const lnrf_hashgrid_desc* d) {
 
 static_assert(sizeof(HashGridDesc) == sizeof(lnrf_hashgrid_desc), "descriptor layout");
 
-// LNRF_HASHGRID_LDS=0 in the environment turns the LDS-staged gather off (A/B measurements); default on
+// experiment builds only (common.h): LNRF_HASHGRID_LDS=0 turns the LDS-staged gather off, LNRF_HASHGRID_XCD=0 selects the
+// plain (chunk, level) grid of the gather
 static bool lds_staging_enabled() {
-  static const bool on = [] {
-    const char* v = getenv("LNRF_HASHGRID_LDS");
-    return !(v && v[0] == '0');
-  }();
+  static const bool on = !exp_env_is("LNRF_HASHGRID_LDS", '0');
   return on;
 }
-
-// LNRF_HASHGRID_XCD=0 in the environment selects the plain (chunk, level) grid of the gather (A/B measurements)
 static bool xcd_mapping_enabled() {
-  static const bool on = [] {
-    const char* v = getenv("LNRF_HASHGRID_XCD");
-    return !(v && v[0] == '0');
-  }();
+  static const bool on = !exp_env_is("LNRF_HASHGRID_XCD", '0');
   return on;
 }
 

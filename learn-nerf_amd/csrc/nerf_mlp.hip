@@ -9,7 +9,6 @@
 //            gradients dy_l and dumps them, (2) a split-K MFMA kernel reduces
 //            dW_l = X_l^T dy_l over all evaluations from the forward/backward dumps.
 // Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / positional encoding.
-#include <stdlib.h>
 #include "nerf_chain.h"
 
 namespace lnrf {
@@ -734,7 +733,7 @@ int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
   {
-    static const int il = [] { const char* v = getenv("LNRF_WGRAD_INTERLEAVE"); return v ? atoi(v) : 0; }();
+    static const int il = exp_env_int("LNRF_WGRAD_INTERLEAVE", 0);  // experiment builds only (common.h)
     lay.interleave = il;
   }
   if (plain)
@@ -768,22 +767,22 @@ extern "C" int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const voi
   WgradArgs a;
   int blocks[13] = {48, 48, 48, 48, 47, 47, 47, 47, 39, 30, 30, 18, 15};
   {
-    // experiment: LNRF_WGRAD_BLOCK_SCALE=<percent> scales the per-problem workgroup counts (default 100 = 512 total)
-    static const int pct = [] { const char* v = getenv("LNRF_WGRAD_BLOCK_SCALE"); return v ? atoi(v) : 100; }();
+    // experiment builds only: LNRF_WGRAD_BLOCK_SCALE=<percent> scales the per-problem workgroup counts (100 = 512 total)
+    static const int pct = exp_env_int("LNRF_WGRAD_BLOCK_SCALE", 100);
     if (pct > 0 && pct != 100)
       for (int i = 0; i < 13; ++i) blocks[i] = (blocks[i] * pct + 50) / 100 < 1 ? 1 : (blocks[i] * pct + 50) / 100;
   }
   const int first = build_wgrad_problems(a, blocks, (n_tiles + 5) / 6);
   (void)rc;
-  // LNRF_WGRAD_ATOMICS=1 keeps the older fp32-atomic epilogue (A/B)
-  static const bool atomics = [] { const char* v = getenv("LNRF_WGRAD_ATOMICS"); return v && v[0] == '1'; }();
+  // experiment builds only: LNRF_WGRAD_ATOMICS=1 keeps the older fp32-atomic epilogue (A/B)
+  static const bool atomics = exp_env_is("LNRF_WGRAD_ATOMICS", '1');
   float* slabs = (atomics || first > kNerfWgradBlocks)
                      ? nullptr
                      : reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + grad_dump_bytes(m));
   // operand loads (fused_chain.h WgStage::load): ordinary for the big (fine-pass) launch, non-temporal for the small one —
   // measured on this model only (the Ref-NeRF launches are faster with non-temporal loads at every size);
-  // LNRF_WGRAD_PLAIN_TILES overrides the threshold (tiles of 32 evaluations)
-  static const int64_t plain_from = [] { const char* v = getenv("LNRF_WGRAD_PLAIN_TILES"); return v ? atoll(v) : 16384ll; }();
+  // (experiment builds: LNRF_WGRAD_PLAIN_TILES overrides the threshold, in tiles of 32 evaluations)
+  static const int64_t plain_from = exp_env_int("LNRF_WGRAD_PLAIN_TILES", 16384);
   return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots}, slabs,
                            n_tiles >= plain_from);
 }

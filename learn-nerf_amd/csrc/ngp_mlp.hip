@@ -10,7 +10,6 @@
 // d loss / d enc feature-major for the hash-grid scatter, and dumps X / dy fragments (about 1 KiB per
 // evaluation) for the shared split-K weight-gradient body.
 // Precision: bf16 operands, fp32 accumulate, fp32 bias / activations / directional encoding.
-#include <stdlib.h>
 
 #include "fused_chain.h"
 
@@ -110,22 +109,35 @@ __host__ __device__ constexpr int ngp_wgrad_parts(int problem) { return (problem
 struct NgpPartsPlan {
   int lo[kNgpLayers], hi[kNgpLayers], parts[kNgpLayers];  // float range [lo, hi) relative to dense_offset
 };
-// grads[dense_off + p] += sum over workgroups and the layer's k-parts of wparts[(wg, part)][p]; blockIdx.y = slice of
-// the workgroup rows (a few atomics per address instead of one per workgroup)
+// grads[dense_off + p] += sum over workgroups and the layer's k-parts of wparts[(wg, part)][p].  One workgroup folds 32
+// neighbouring parameters: thread (slice s, parameter) sums the rows of slice s of the workgroups in order, the eight
+// slice sums meet in LDS and are added in order by slice 0, which owns the parameter (plain read-modify-write).  Every
+// addition has a fixed place, so the Dense gradients of the fused backward are bit-reproducible.
+constexpr int kNgpReduceSlices = 8;
 __global__ __launch_bounds__(256) void ngp_wparts_reduce_kernel(const float* __restrict__ wparts, int n_wg, int pstride,
                                                                 int n_params, NgpPartsPlan plan,
                                                                 float* __restrict__ grads_dense) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n_params) return;
+  __shared__ float part[kNgpReduceSlices][32];
+  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int p = blockIdx.x * 32 + pl;
   int parts = 0;
+  if (p < n_params) {
 #pragma unroll
-  for (int l = 0; l < kNgpLayers; ++l)
-    if (p >= plan.lo[l] && p < plan.hi[l]) parts = plan.parts[l];
-  const int w0 = (int)((int64_t)n_wg * blockIdx.y / gridDim.y), w1 = (int)((int64_t)n_wg * (blockIdx.y + 1) / gridDim.y);
+    for (int l = 0; l < kNgpLayers; ++l)
+      if (p >= plan.lo[l] && p < plan.hi[l]) parts = plan.parts[l];
+  }
+  const int w0 = (int)((int64_t)n_wg * sl / kNgpReduceSlices), w1 = (int)((int64_t)n_wg * (sl + 1) / kNgpReduceSlices);
   float acc = 0.0f;
   for (int w = w0; w < w1; ++w)
     for (int q = 0; q < parts; ++q) acc += wparts[((int64_t)w * kNgpMaxParts + q) * pstride + p];
-  if (parts > 0) atomicAdd(grads_dense + p, acc);
+  part[sl][pl] = acc;
+  __syncthreads();
+  if (sl == 0 && parts > 0) {
+    float tot = part[0][pl];
+#pragma unroll
+    for (int q = 1; q < kNgpReduceSlices; ++q) tot += part[q][pl];
+    grads_dense[p] += tot;
+  }
 }
 
 constexpr int kNgpStageStep = 8 * kFragBytes;                 // fused mode: staging bytes per wave (<= 8 fragments per layer)
@@ -693,9 +705,33 @@ extern "C" int64_t lnrf_ngp_mlp_packed_bytes(const lnrf_ngp_mlp_desc* desc) {
 }
 static int64_t ngp_lmax_bytes(int64_t n_tiles) { return (n_tiles + kWaves - 1) / kWaves * 16 * (int64_t)sizeof(float); }
 
+// The two-launch backward (fragment dumps + split-K weight-gradient kernel with fp32 atomics) is the A/B partner of the
+// persistent backward; only experiment builds (common.h) can select it, with LNRF_NGP_WGRAD=split.
+static bool ngp_fused_wgrad_enabled() {
+  static const bool on = !exp_env_is("LNRF_NGP_WGRAD", 's');
+  return on;
+}
+// scratch = [partial dW rows of the persistent backward | (experiment builds: fragment dumps of the two-launch path)]
+// then one row of 16 per-level maxima per workgroup.  At most kNgpMaxPersistent workgroups form partial rows.
+constexpr int kNgpMaxPersistent = 512;
+static int ngp_dense_params(const lnrf_ngp_mlp_desc* d) {
+  const NgpOffsets o = ngp_offsets(d);
+  return (int)(o.b[kNgpLayers - 1] + ngp_out_dim(kNgpLayers - 1) - d->dense_offset);
+}
+static int ngp_pstride(const lnrf_ngp_mlp_desc* d) { return (ngp_dense_params(d) + 63) / 64 * 64; }
+static int64_t ngp_lmax_off(const lnrf_ngp_mlp_desc* d, int64_t n_tiles) {
+  int64_t rows = n_tiles / kWaves;
+  if (rows > kNgpMaxPersistent) rows = kNgpMaxPersistent;
+  int64_t bytes = rows * kNgpMaxParts * ngp_pstride(d) * (int64_t)sizeof(float);
+  if (!ngp_fused_wgrad_enabled()) {
+    const int64_t dumps = (int64_t)kNgpSlots * n_tiles * kFragBytes;
+    if (dumps > bytes) bytes = dumps;
+  }
+  return (bytes + 255) / 256 * 256;
+}
+
 extern "C" int64_t lnrf_ngp_mlp_scratch_bytes(const lnrf_ngp_mlp_desc* desc, int64_t m) {
-  // fragment dumps of the two-launch path + one row of 16 per-level maxima per workgroup (either path)
-  return ngp_supported(desc) ? (int64_t)kNgpSlots * ngp_tiles(m) * kFragBytes + ngp_lmax_bytes(ngp_tiles(m)) : -1;
+  return ngp_supported(desc) ? ngp_lmax_off(desc, ngp_tiles(m)) + ngp_lmax_bytes(ngp_tiles(m)) : -1;
 }
 
 extern "C" int lnrf_ngp_mlp_pack(const lnrf_ngp_mlp_desc* desc, const float* params, void* packed,
@@ -735,15 +771,6 @@ extern "C" int lnrf_ngp_mlp_fwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   return LNRF_OK;
 }
 
-// LNRF_NGP_WGRAD=split in the environment selects the older two-launch backward (dumps + split-K kernel)
-static bool ngp_fused_wgrad_enabled() {
-  static const bool on = [] {
-    const char* v = getenv("LNRF_NGP_WGRAD");
-    return !(v && v[0] == 's');
-  }();
-  return on;
-}
-
 extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t,
                                 const float* d, const float* g_density, const float* g_rgb, int64_t m,
                                 void* scratch, float* g_enc_t, float* level_absmax, float* grads,
@@ -758,7 +785,7 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
   int rc;
   // per-workgroup rows of level maxima live behind the dumps in the scratch buffer
   float* lmax_parts = level_absmax ? reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) +
-                                                              (int64_t)kNgpSlots * n_tiles * kFragBytes)
+                                                              ngp_lmax_off(desc, n_tiles))
                                    : nullptr;
   const int n_levels = desc->enc_dim / 2;
   // weight-gradient problems (five Dense layers)
@@ -796,6 +823,7 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
     if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
     int64_t nb = n_tiles / kWaves;
     if (nb > cus) nb = cus;
+    if (nb > kNgpMaxPersistent) nb = kNgpMaxPersistent;
     const dim3 pgrid((unsigned)nb);
     // partial dW rows (workgroup, k-part) live where the two-launch path keeps its dumps: nb <= n_tiles / 8 rows of
     // 4 x pstride floats against 8 x 34 KiB of dump room per workgroup
@@ -806,12 +834,8 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
       plan.hi[i] = (int)(off.b[layer] - desc->dense_offset) + ngp_out_dim(layer);
       plan.parts[i] = ngp_wgrad_parts(i);
     }
-    const int n_params = plan.hi[3];  // Dense_4 is the last layer of the vector
-    const int pstride = (n_params + 63) / 64 * 64;
-    if ((int64_t)nb * kNgpMaxParts * pstride * (int64_t)sizeof(float) > (int64_t)kNgpSlots * n_tiles * kFragBytes) {
-      set_error("lnrf_ngp_mlp_bwd: scratch too small for the partial weight gradients");
-      return LNRF_ERR_ARG;
-    }
+    const int n_params = ngp_dense_params(desc);
+    const int pstride = ngp_pstride(desc);
     float* wparts = reinterpret_cast<float*>(scratch);
     if (desc->enc_dim <= 16) {
       rc = ngp_ensure_lds(ngp_mlp_kernel<1, true, true>, kNgpFusedLds);
@@ -827,7 +851,7 @@ extern "C" int lnrf_ngp_mlp_bwd(const lnrf_ngp_mlp_desc* desc, const void* packe
                          lmax_parts, a, wparts, pstride, (int64_t)desc->dense_offset);
     }
     LNRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ngp_wparts_reduce_kernel, dim3((unsigned)((n_params + 255) / 256), 8), dim3(256), 0, st, wparts,
+    hipLaunchKernelGGL(ngp_wparts_reduce_kernel, dim3((unsigned)((n_params + 31) / 32)), dim3(256), 0, st, wparts,
                        (int)nb, pstride, n_params, plan, grads + desc->dense_offset);
     LNRF_LAUNCH_CHECK();
     if (lmax_parts) {

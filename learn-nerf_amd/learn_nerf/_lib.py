@@ -99,10 +99,6 @@ PROTOTYPES = {
     "lnrf_nerf_mlp_fwd_split": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, c_int64, _P, c_int32, c_int64, _P, _P,
                                           _P]),
     "lnrf_nerf_mlp_bwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
-    "lnrf_nerf_bwd_fused_workspace_bytes": (c_int64, [POINTER(NerfShape)]),
-    "lnrf_nerf_mlp_bwd_fused": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
-    "lnrf_nerf_bwd_fused_tune": (c_int32, [c_int32, c_int32]),
-    "lnrf_nerf_bwd_fused_debug": (c_int32, [c_int32]),
     "lnrf_nerf_mlp_bwd_chain": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "lnrf_nerf_mlp_bwd_weights": (c_int32, [POINTER(NerfShape), _P, _P, c_int64, _P, _P]),
     "lnrf_ngp_mlp_packed_bytes": (c_int64, [POINTER(NgpMlpDesc)]),

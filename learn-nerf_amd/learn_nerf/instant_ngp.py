@@ -17,6 +17,7 @@ import torch
 
 from . import _lib as L
 from . import _prof
+from . import _ws
 from . import ops
 from .model import ModelBase
 from .params import lecun_normal_
@@ -183,11 +184,12 @@ class InstantNGPModel(ModelBase):
         m, dev = ctx["x"].shape[0], grad_flat.device
         lf = desc.enc_dim
         with _prof.section(f"{self.tag}_mlp_bwd"):
-            nbytes = L.lib().lnrf_ngp_mlp_scratch_bytes(ctypes.byref(desc), m)
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            lease = _ws.lease("ngp_scratch", L.lib().lnrf_ngp_mlp_scratch_bytes(ctypes.byref(desc), m), dev)
+            scratch = lease.buf
             if POISON_SCRATCH:  # tests: every word the kernels read back must have been written by them
                 scratch.fill_(0xFF)
-            g_enc_t = torch.empty((lf, m), dtype=F32, device=dev)
+            glease = _ws.lease("ngp_g_enc", lf * m * 4, dev)
+            g_enc_t = glease.buf.view(F32).view(lf, m)
             level_absmax = torch.zeros(lf // 2, dtype=F32, device=dev)  # the scatter's fixed-point scale per level
             gd = g_density.reshape(-1).contiguous()
             gr = g_rgb.reshape(-1, 3).contiguous()

@@ -23,6 +23,7 @@ import torch
 
 from . import _lib as L
 from . import _prof
+from . import _ws
 from . import ops
 from .params import ParamTree, as_generator, build_tree, default_device, flat_of, lecun_normal_, spec_size
 
@@ -87,27 +88,6 @@ class ModelBase:
         raise NotImplementedError
 
 
-_FUSED_WS = {}
-
-
-def _fused_bwd_workspace(shape, device) -> torch.Tensor:
-    """One workspace per device for lnrf_nerf_mlp_bwd_fused (control words + Infinity-Cache-resident rings); calls on
-    one stream may share it.  fused_bwd_status() reads its status word."""
-    key = (device.type, device.index)
-    if key not in _FUSED_WS:
-        nbytes = L.lib().lnrf_nerf_bwd_fused_workspace_bytes(ctypes.byref(shape))
-        _FUSED_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    return _FUSED_WS[key]
-
-
-def fused_bwd_status(device=None) -> int:
-    """Status word of the last lnrf_nerf_mlp_bwd_fused launch on `device` (synchronises): 0 = every hand-off completed;
-    otherwise the code of the bounded wait that gave up (gradients of that call are invalid)."""
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    ws = _FUSED_WS.get((device.type, device.index))
-    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
-
-
 def _is_leafy(d) -> bool:
     return any(isinstance(v, torch.Tensor) for v in d.values())
 
@@ -138,9 +118,8 @@ class NeRFModel(ModelBase):
     d_freqs: int = 4
     precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
     render_precision: str = "bf16x3"  # fused path, forward without backward: "bf16x3" (split) | "bf16"
-    # fused path, backward: "fused" = one persistent launch (chain + weight gradients, lnrf_nerf_mlp_bwd_fused) |
-    # "split" = separate chain and weight-gradient launches through HBM (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
-    backward_kernel: str = os.environ.get("LNRF_NERF_BACKWARD", "split")
+    # fused path, backward: "split" = separate chain and weight-gradient launches (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
+    backward_kernel: str = "split"
     tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
     # TrainLoop may run the coarse backward on a second stream beside the fine forward; for this model every kernel
     # already fills all 256 CUs at one workgroup per CU, so the two streams only time-slice (5.012 / 5.020 ms without,
@@ -263,17 +242,17 @@ class NeRFModel(ModelBase):
                     L.ptr(ts), t, m, L.ptr(density), L.ptr(rgb), L.stream()), "nerf_mlp_fwd_split")
             return density, rgb, None
         packed = self.packed_weights(flat)
-        save_buf = None
-        if save:
-            nbytes = L.lib().lnrf_nerf_save_bytes(ctypes.byref(shape), m)
-            save_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        save_buf, save_lease = None, None
+        if save:  # leased for the life of the backward context (a step-persistent block, see _ws.py)
+            save_lease = _ws.lease("nerf_save", L.lib().lnrf_nerf_save_bytes(ctypes.byref(shape), m), dev)
+            save_buf = save_lease.buf
         with _prof.section(f"{self.tag}_fwd"):
             L.check(L.lib().lnrf_nerf_mlp_fwd(
                 ctypes.byref(shape), L.ptr(packed, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride,
                 L.ptr(ts), t, m, L.ptr(density), L.ptr(rgb), L.ptr(save_buf, torch.uint8), L.stream()),
                 "nerf_mlp_fwd")
-        ctx = (dict(kind="fused", packed=packed, save=save_buf, density=density, rgb=rgb, m=m, tag=self.tag)
-               if save else None)
+        ctx = (dict(kind="fused", packed=packed, save=save_buf, save_lease=save_lease, density=density, rgb=rgb, m=m,
+                    tag=self.tag) if save else None)
         return density, rgb, ctx
 
     def forward_points(self, flat, x, d, save: bool):
@@ -295,18 +274,8 @@ class NeRFModel(ModelBase):
             shape = self._shape_struct()
             m = ctx["m"]
             tag = ctx.get("tag", "mlp")
-            if self.backward_kernel == "fused":
-                ws = _fused_bwd_workspace(shape, grad_flat.device)
-                with _prof.section(f"{tag}_bwd_fused"):
-                    rc = L.lib().lnrf_nerf_mlp_bwd_fused(
-                        ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
-                        L.ptr(ctx["density"]), L.ptr(ctx["rgb"]), L.ptr(g_density.reshape(-1)),
-                        L.ptr(g_rgb.reshape(-1, 3)), m, L.ptr(ws, torch.uint8), L.ptr(grad_flat), L.stream())
-                if rc != L.ERR_UNSUPPORTED:
-                    L.check(rc, "nerf_mlp_bwd_fused")
-                    return
-            nbytes = L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m)
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=grad_flat.device)
+            lease = _ws.lease("nerf_bwd", L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), grad_flat.device)
+            scratch = lease.buf
             with _prof.section(f"{tag}_bwd_chain"):
                 L.check(L.lib().lnrf_nerf_mlp_bwd_chain(
                     ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
@@ -316,6 +285,7 @@ class NeRFModel(ModelBase):
                 L.check(L.lib().lnrf_nerf_mlp_bwd_weights(
                     ctypes.byref(shape), L.ptr(ctx["save"], torch.uint8), L.ptr(scratch, torch.uint8), m,
                     L.ptr(grad_flat), L.stream()), "nerf_mlp_bwd_weights")
+            lease.release()
             return
         self._dense_bwd(ctx, g_density, g_rgb, grad_flat)
 

@@ -10,6 +10,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
+from . import _ws
 
 F32 = torch.float32
 
@@ -324,7 +325,8 @@ def hashgrid_bwd(desc, x: torch.Tensor, g_enc_t: torch.Tensor, g_tables: torch.T
 
     m = x.shape[0]
     nbytes = L.lib().lnrf_hashgrid_bwd_scratch_bytes(ctypes.byref(desc), m)
-    scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=_dev(x))
+    lease = _ws.lease("hashgrid_bwd", max(int(nbytes), 16), _dev(x))
+    scratch = lease.buf
     if level_absmax is not None and (u is not None or level_absmax.numel() < desc.n_levels):
         raise ValueError("level_absmax: one float per level, plain scatter only")
     L.check(L.lib().lnrf_hashgrid_bwd_bucketed(ctypes.byref(desc), L.ptr(x), L.ptr(u), m, L.ptr(g_enc_t),

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib as L
 from . import _prof
+from . import _ws
 from . import ops
 from .model import ModelBase
 from .params import lecun_normal_
@@ -147,8 +148,10 @@ class RefNERFModel(RefNERFBase):
         ns = self.input_layers + self.mid_layers
         packed = self.packed_trunk(flat)
         shape = L.NerfShape(5, 4, 256, 128, 10, 4)  # the trunk's buffers have NeRFModel's layout
-        save_buf = torch.empty(lib.lnrf_nerf_save_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
-        cdump = torch.empty(lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+        # GB-sized blocks are leased from step-persistent pools (_ws.py) and stay busy as long as the context lives
+        leases = [_ws.lease("ref_save", lib.lnrf_nerf_save_bytes(ctypes.byref(shape), m), dev),
+                  _ws.lease("ref_cdump", lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dev)]
+        save_buf, cdump = leases[0].buf, leases[1].buf
         width = hd + ne + 1
         ld = (width + 3) // 4 * 4  # rows 16-byte aligned for the fused kernels' float4 accesses
         dir_full = torch.empty((m, ld), dtype=F32, device=dev)
@@ -165,7 +168,8 @@ class RefNERFModel(RefNERFBase):
         with _prof.section(f"{self.tag}_head_fwd"), ops.dense_precision(self.precision):
             density, diffuse, spectral, aux2 = ops.refnerf_head_fwd(dir_in, nraw, d, self.sh_degree, dir_in[:, hd:])
             if self._use_fused_dir():  # ref_nerf.py:105-107 on the fused chain
-                dsave = torch.empty(lib.lnrf_refnerf_dir_save_bytes(m), dtype=torch.uint8, device=dev)
+                leases.append(_ws.lease("ref_dsave", lib.lnrf_refnerf_dir_save_bytes(m), dev))
+                dsave = leases[-1].buf
                 dir_out = torch.empty((m, 3), dtype=F32, device=dev)
                 L.check(lib.lnrf_refnerf_dir_fwd(L.ptr(packed, torch.uint8), L.ptr(dir_full), ld, m,
                                                  L.ptr(dsave, torch.uint8), L.ptr(dir_out), L.stream()),
@@ -179,7 +183,7 @@ class RefNERFModel(RefNERFBase):
         if save:
             ctx = dict(kind="fused", flat=flat, packed=packed, x=x, d=d, save=save_buf, cdump=cdump, dir_in=dir_in,
                        ld=ld, nraw=nraw, density=density, diffuse=diffuse, spectral=spectral, hcol=hcol,
-                       dir_out=dir_out, dsave=dsave)
+                       dir_out=dir_out, dsave=dsave, leases=leases)
         return density, rgb, aux, ctx
 
     def _fused_backward(self, ctx, g_density, g_rgb, g_aux, grad_flat):
@@ -199,7 +203,8 @@ class RefNERFModel(RefNERFBase):
                                                      g_rgb.reshape(-1, 3).contiguous())
             g_full = torch.empty((m, ld), dtype=F32, device=dev)
             if ctx["dsave"] is not None:
-                dscratch = torch.empty(lib.lnrf_refnerf_dir_scratch_bytes(m), dtype=torch.uint8, device=dev)
+                dlease = _ws.lease("ref_dscratch", lib.lnrf_refnerf_dir_scratch_bytes(m), dev)
+                dscratch = dlease.buf
                 L.check(lib.lnrf_refnerf_dir_bwd(L.ptr(packed, torch.uint8), L.ptr(ctx["dsave"], torch.uint8),
                                                  L.ptr(g_do), m, L.ptr(dscratch, torch.uint8), L.ptr(g_full), ld,
                                                  L.ptr(grad_flat), L.stream()), "refnerf_dir_bwd")
@@ -213,12 +218,14 @@ class RefNERFModel(RefNERFBase):
                                      g_sp, g_dir_in[:, hd:], g_aux2, g_dir_in)
         shape = L.NerfShape(5, 4, 256, 128, 10, 4)
         with _prof.section(f"{self.tag}_spatial_bwd"):  # first-order: d L / d spatial_out -> Dense_8 .. Dense_0
-            scratch = torch.empty(lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+            slease = _ws.lease("ref_scratch", lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dev)
+            scratch = slease.buf
             L.check(lib.lnrf_refnerf_trunk_bwd(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8), L.ptr(g_full),
                                                ld, m, L.ptr(scratch, torch.uint8), L.ptr(grad_flat), L.stream()),
                     "refnerf_trunk_bwd")
         with _prof.section(f"{self.tag}_normal_bwd"):  # second-order: through n_raw (u = d L / d n_raw)
-            tscratch = torch.empty(lib.lnrf_nerf_save_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device=dev)
+            tlease = _ws.lease("ref_tscratch", lib.lnrf_nerf_save_bytes(ctypes.byref(shape), m), dev)
+            tscratch = tlease.buf
             L.check(lib.lnrf_refnerf_normal_bwd(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8),
                                                 L.ptr(cdump, torch.uint8), L.ptr(x), L.ptr(u), m,
                                                 L.ptr(tscratch, torch.uint8), L.ptr(grad_flat), L.stream()),

@@ -240,30 +240,3 @@ def test_backward_is_bit_reproducible(m):
         grads.append(g)
     assert grads[0].abs().max().item() > 0
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
-
-
-@pytest.mark.parametrize("m", [32, 8192 + 17, 70000])
-def test_persistent_fused_backward_equals_two_launch_backward(m):
-    """lnrf_nerf_mlp_bwd_fused (one persistent launch: chain workgroups hand dy to weight-gradient workgroups through
-    ring buffers) must give the gradients of lnrf_nerf_mlp_bwd_chain + _bwd_weights: same bf16 operands, same fp32
-    MFMA accumulation per 32-evaluation tile, only the order of the fp32 atomic adds differs.  The status word of the
-    hand-off protocol must stay 0 (no bounded wait gave up)."""
-    from learn_nerf.model import fused_bwd_status
-
-    model, params, flat = make_model("bf16")
-    x, d, gen = make_points(m, seed=11)
-    g_dens = torch.randn(m, generator=gen).float().cuda()
-    g_rgb = torch.randn(m, 3, generator=gen).float().cuda()
-    grads = {}
-    for kind in ("split", "fused"):
-        model.backward_kernel = kind
-        _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
-        g = torch.zeros_like(flat)
-        model.backward(ctx, g_dens, g_rgb, None, g)
-        model.backward(ctx, g_dens, g_rgb, None, g)  # twice: the control block is re-zeroed by every call
-        torch.cuda.synchronize()
-        grads[kind] = g
-    assert fused_bwd_status() == 0
-    rel = ((grads["fused"] - grads["split"]).norm() / grads["split"].norm()).item()
-    print(f"m={m}: persistent vs two-launch backward, rel L2 {rel:.2e}")
-    assert rel < 1e-5
