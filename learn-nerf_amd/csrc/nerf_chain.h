@@ -46,7 +46,8 @@ struct GlobalDumpSink {
 // SINK: begin_flag<F>() before the first store of flag F, store(slot, frag), end_flag<F>() after its last store.
 // `ring` must be freshly constructed; the caller provides the workgroup barrier that separates two uses of the
 // weight ring's LDS.
-template <class SINK, class RING>
+// HEAD_ONLY: stop after flag 1 (dy11, dy10m, dz): the head launch of the layer-stationary backward (nerf_bwd_ls.hip).
+template <class SINK, class RING, bool HEAD_ONLY = false>
 __device__ __forceinline__ void bwd_chain_tile(RING& ring, SINK& sink, const char* __restrict__ save,
                                                int64_t save_tiles, const float* __restrict__ density,
                                                const float* __restrict__ rgb, const float* __restrict__ g_density,
@@ -122,6 +123,7 @@ __device__ __forceinline__ void bwd_chain_tile(RING& ring, SINK& sink, const cha
       });
   sink.template end_flag<1>();
 
+  if constexpr (HEAD_ONLY) return;
   // T2..T9: Dense_l^T for l = 8..1: dy_l (in) -> dh_{l-1}, masked by relu(h_{l-1}) -> dy_{l-1}
   auto back = [&](auto t_, bf16x8(&in)[16], bf16x8(&out)[16]) {
     constexpr int TT = decltype(t_)::value;

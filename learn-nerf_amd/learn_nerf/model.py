@@ -88,6 +88,17 @@ class ModelBase:
         raise NotImplementedError
 
 
+def ls_status(ctx) -> int:
+    """Status word of the last layer-stationary backward of this context (synchronises): 0 = every hand-off completed,
+    otherwise the code of the bounded wait that gave up (the gradients of that call are invalid)."""
+    buf = ctx.get("ls_scratch")
+    if buf is None:
+        return 0
+    shape = L.NerfShape(5, 4, 256, 128, 10, 4)
+    off = L.lib().lnrf_nerf_bwd_ls_status_offset(ctypes.byref(shape), ctx["m"])
+    return int(buf[off:off + 4].view(torch.int32).item())
+
+
 def _is_leafy(d) -> bool:
     return any(isinstance(v, torch.Tensor) for v in d.values())
 
@@ -118,7 +129,8 @@ class NeRFModel(ModelBase):
     d_freqs: int = 4
     precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
     render_precision: str = "bf16x3"  # fused path, forward without backward: "bf16x3" (split) | "bf16"
-    # fused path, backward: "split" = separate chain and weight-gradient launches (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
+    # fused path, backward: "ls" = layer-stationary pipeline (lnrf_nerf_mlp_bwd_ls: one CU per Dense layer, dW in
+    # registers) | "split" = separate chain and weight-gradient launches through HBM (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
     backward_kernel: str = "split"
     tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
     # TrainLoop may run the coarse backward on a second stream beside the fine forward; for this model every kernel
@@ -274,6 +286,20 @@ class NeRFModel(ModelBase):
             shape = self._shape_struct()
             m = ctx["m"]
             tag = ctx.get("tag", "mlp")
+            if self.backward_kernel == "ls":
+                lease = _ws.lease("nerf_bwd_ls", L.lib().lnrf_nerf_bwd_ls_scratch_bytes(ctypes.byref(shape), m),
+                                  grad_flat.device)
+                with _prof.section(f"{tag}_bwd_ls"):
+                    L.check(L.lib().lnrf_nerf_mlp_bwd_ls(
+                        ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8),
+                        L.ptr(ctx["density"]), L.ptr(ctx["rgb"]), L.ptr(g_density.reshape(-1)),
+                        L.ptr(g_rgb.reshape(-1, 3)), m, L.ptr(lease.buf, torch.uint8), L.ptr(grad_flat), L.stream()),
+                        "nerf_mlp_bwd_ls")
+                ctx["ls_scratch"] = lease.buf  # ls_status(ctx) reads the hand-off status word from it
+                lease.release()
+                return
+            if self.backward_kernel != "split":
+                raise ValueError(f"unknown backward_kernel {self.backward_kernel!r}")
             lease = _ws.lease("nerf_bwd", L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), grad_flat.device)
             scratch = lease.buf
             with _prof.section(f"{tag}_bwd_chain"):

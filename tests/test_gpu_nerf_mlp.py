@@ -240,3 +240,36 @@ def test_backward_is_bit_reproducible(m):
         grads.append(g)
     assert grads[0].abs().max().item() > 0
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+@pytest.mark.parametrize("m", [32, 8192 + 17, 70000, 262144])
+def test_layer_stationary_backward_equals_two_launch_backward(m):
+    """lnrf_nerf_mlp_bwd_ls (head launch + one persistent launch in which every CU owns one Dense layer and the tiles
+    pass from CU to CU) must give the gradients of lnrf_nerf_mlp_bwd_chain + _bwd_weights: the same bf16 operands and the
+    same fp32 MFMA accumulation per 32-evaluation tile, so the pre-activation gradients are identical and only the order
+    of the fp32 partial sums differs.  Per Dense layer; the hand-off status word must stay 0; and the result must be
+    bit-reproducible (fixed-order fold of the per-pipeline partial sums), also on a second call with the same scratch."""
+    from learn_nerf.model import ls_status
+
+    model, params, flat = make_model("bf16")
+    x, d, gen = make_points(m, seed=11)
+    g_dens = torch.randn(m, generator=gen).float().cuda()
+    g_rgb = torch.randn(m, 3, generator=gen).float().cuda()
+    grads = {}
+    for kind in ("split", "ls", "ls_again"):
+        model.backward_kernel = kind.split("_")[0]
+        _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+        g = torch.zeros_like(flat)
+        model.backward(ctx, g_dens, g_rgb, None, g)
+        torch.cuda.synchronize()
+        if kind != "split":
+            assert ls_status(ctx) == 0
+        grads[kind] = g
+    off = 0
+    for i, (fi, fo) in enumerate(model.layer_dims()):
+        for name, n in (("kernel", fi * fo), ("bias", fo)):
+            a, b = grads["ls"][off:off + n], grads["split"][off:off + n]
+            rel = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+            assert rel < 1e-5, (f"Dense_{i}.{name}", rel)
+            off += n
+    assert torch.equal(grads["ls"], grads["ls_again"])
