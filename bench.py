@@ -156,7 +156,7 @@ def comm_abi_probe(dist, rank, world, local_rank, device):
     return "timeout after 60 s (abandoned)", False
 
 
-def build_loop(workload, precision, table_log2, device):
+def build_loop(workload, precision, table_log2, device, backward="ls"):
     from learn_nerf.model import NeRFModel
     from learn_nerf.train import TrainLoop
 
@@ -176,7 +176,8 @@ def build_loop(workload, precision, table_log2, device):
         return TrainLoop(RefNERFModel(sh_degree=4, precision=precision),
                          RefNERFModel(sh_degree=4, precision=precision), init_rng=0, lr=1e-4, coarse_ts=COARSE,
                          fine_ts=FINE, device=device)
-    return TrainLoop(NeRFModel(precision=precision), NeRFModel(precision=precision), init_rng=0,
+    return TrainLoop(NeRFModel(precision=precision, backward_kernel=backward),
+                     NeRFModel(precision=precision, backward_kernel=backward), init_rng=0,
                      lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, device=device)
 
 
@@ -290,6 +291,9 @@ def main():
                     help="nerf = BASELINE configs[1] (the metric's config, default); ngp = configs[2] hash-grid path; "
                          "refnerf = configs[3] RefNERFModel (fused spatial block)")
     ap.add_argument("--table_log2", type=int, default=19, help="ngp: log2 of the hash table size (configs[2]: 19)")
+    ap.add_argument("--backward", default="ls", choices=["ls", "split"],
+                    help="nerf: NeRFModel backward = layer-stationary pipeline (default) or the older chain + weight-gradient "
+                         "launches (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short ngp / refnerf legs")
@@ -332,7 +336,7 @@ def main():
     from learn_nerf import _prof
 
     n = args.rays
-    loop = build_loop(args.workload, args.precision, args.table_log2, device)
+    loop = build_loop(args.workload, args.precision, args.table_log2, device, args.backward)
     if world > 1:  # same initial parameters everywhere (init is seeded, broadcast for safety)
         dist.broadcast(loop.flat, src=0)
     step = loop.step_fn(BBOX_MIN, BBOX_MAX)
@@ -369,6 +373,8 @@ def main():
         for name, (cnt, ms) in prof.items():
             lvl = "coarse" if name.startswith("coarse") else ("fine" if name.startswith("fine") else None)
             flops = None
+            if name == "bwd_ls":  # both models' backward in one family of launches (head, pipeline, small problems, folds)
+                flops = (m_c + m_f) * 2 * (MAC_DGRAD_PER_EVAL + MAC_WGRAD_PER_EVAL)
             if lvl:
                 m = m_c if lvl == "coarse" else m_f
                 if name.endswith("_fwd"):
@@ -391,15 +397,18 @@ def main():
             # Design HBM bytes per 32-evaluation tile of each kernel family:
             # forward writes the 167 KiB save block, the backward chain reads 9 KiB of masks and writes
             # 156 KiB of dy, the weight-gradient kernel reads X and dy fragments (344 KiB).
-            tile_bytes = {"_fwd": 167 * 1024, "_bwd_chain": (156 + 9) * 1024, "_bwd_weights": 344 * 1024}
+            # layer-stationary backward: head (9 + 28 KiB), pipeline (reads 128 KiB of X + 16 of dy8, writes 128 of dy; the
+            # dy reads behind the producer are served on chip), small problems (88 KiB)
+            tile_bytes = {"_fwd": 167 * 1024, "_bwd_chain": (156 + 9) * 1024, "_bwd_weights": 344 * 1024,
+                          "bwd_ls": (37 + 272 + 88) * 1024}
             for name, v in timed.items():
-                m = m_c if name.startswith("coarse") else m_f
+                m = m_c if name.startswith("coarse") else (m_c + m_f if name == "bwd_ls" else m_f)
                 for suffix, b in tile_bytes.items():
                     if name.endswith(suffix):
                         v["GBps"] = round((m / 32) * b / (v["ms"] * 1e-3) / 1e9, 1)
             dom = max(timed, key=lambda k: timed[k]["ms"])
             traffic, traffic_source = None, None
-            for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            for cand in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
                 pmc = os.path.join(ROOT, "profiles", cand)
                 if os.path.exists(pmc) and n == RAYS_PER_GPU:
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")

@@ -61,6 +61,22 @@ struct LsArgs {
   int n_jobs, total_pipelines;
 };
 
+// In-kernel timeline (debug builds with -DLNRF_TIMELINE only, tools/ls_timeline_probe.py): the four waves of pipeline 0's
+// stages 0, 3 and 7 stamp s_memtime at 8 points of iterations kLsTlIter0 .. + 15; compiled out of the product library.
+#ifdef LNRF_TIMELINE
+__device__ unsigned long long* g_ls_timeline_buf = nullptr;  // [3 stages][4 waves][16 iterations][8 stamps]
+constexpr int kLsTlIter0 = 200;
+#define LS_STAMP(k)                                                                                          \
+  do {                                                                                                       \
+    if (tl_on && i >= kLsTlIter0 && i < kLsTlIter0 + 16) {                                                   \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
+      if (lane == 0) tl_buf[((tl_sel * 4 + wave) * 16 + (i - kLsTlIter0)) * 8 + (k)] = t_;                     \
+    }                                                                                                        \
+  } while (0)
+#else
+#define LS_STAMP(k) ((void)0)
+#endif
+
 // ---- inline-asm vector memory (hand-counted, see the header) ------------------------------------------------------
 // 1 KiB LDS-DMA: lane i fetches 16 bytes at base + voff + IMM and they land at lds_dst + IMM + 16 i (the instruction
 // offset applies to the global AND the LDS address)
@@ -83,8 +99,10 @@ __device__ __forceinline__ void ls_poll(const unsigned* word, unsigned lds_dst) 
 }
 template <int IMM, bool SC1>
 __device__ __forceinline__ void ls_store16(char* base, unsigned voff, u32x4 v) {
-  if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3 sc1" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3 nt" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
+  // The s_nop covers the hazard the compiler handles for its own stores and cannot see here: a store of more than 64 bits
+  // reads its data registers for a few cycles after issue, and the next instruction may be a VALU write of one of them.
+  if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3 sc1\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
 }
 __device__ __forceinline__ void ls_flag_store(unsigned* word, unsigned value) {
   unsigned zero = 0u;
@@ -104,11 +122,26 @@ __device__ __forceinline__ unsigned lds_u32(int off) {
       (__attribute__((address_space(3))) char*)smem + off);
 }
 
-// bf16 pair mask of an activation dword: 0xFFFF where the half is non-zero (ReLU output > 0)
-__device__ __forceinline__ unsigned relu_pair_mask(unsigned x) {
-  const unsigned lo = (x & 0xFFFFu) != 0u ? 0x0000FFFFu : 0u;
-  const unsigned hi = (x >> 16) != 0u ? 0xFFFF0000u : 0u;
-  return lo | hi;
+// dy pair = bf16 pair `pk`, each half kept where the matching half of the activation dword `x` is non-zero (ReLU output
+// > 0) and zeroed elsewhere: min(x, 1) is 0 / 1 per half, times the bf16 bits.  Two packed VALU operations.
+__device__ __forceinline__ unsigned relu_gate_pair(unsigned pk, unsigned x) {
+  unsigned t, r;
+  const unsigned ones = 0x00010001u;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(x), "v"(ones));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(t), "v"(pk));
+  return r;
+}
+
+// The input-gradient MFMAs are inline asm so that their accumulators are VGPR tuples: the 256 accumulator registers hold
+// dW, and the compiler would otherwise swap two dW tiles between the files around every tile (64 copies) and read the
+// results back one register at a time.  Exactly-same-register accumulate chains need no software wait states; the first
+// VALU read of a result is placed (scheduling fences) behind two later MFMAs, i.e. after the producing MFMA has left the
+// pipe, plus an explicit s_nop.
+__device__ __forceinline__ void mfma_vgpr_first(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_vgpr(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
 __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
@@ -177,6 +210,11 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
     return;
   }
 
+#ifdef LNRF_TIMELINE
+  unsigned long long* tl_buf = g_ls_timeline_buf;
+  const int tl_sel = stage == 0 ? 0 : (stage == 3 ? 1 : 2);
+  const bool tl_on = tl_buf != nullptr && gp == 0 && (stage == 0 || stage == 3 || stage == 7);
+#endif
   // tiles of my input known to be complete (stage 0 reads the head kernel's dump: all there before the launch)
   int ready = stage == 0 ? n_my : 0;
   bool failed = false;
@@ -208,75 +246,145 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
   ls_barrier();
 
   // ---- steady state: one tile per iteration ---------------------------------------------------------------------
-  // vector-memory operations of iteration i, in issue order: [wave 0: poll] 8 DMA loads of tile i + kLsDist, 4 stores of
-  // dy_{l-1} of tile i, [wave 0, after the barrier: flag store].  The wait at the end of iteration i leaves the operations of
+  // vector-memory operations of iteration i: [wave 0: poll] 8 DMA loads of tile i + kLsDist, 4 stores of dy_{l-1} of tile
+  // i, [wave 0, after the barrier: flag store].  The wait at the end of iteration i leaves the operations of
   // the last kLsLag iterations in flight.
   for (int i = 0; i < n_my; ++i) {
     const int buf = i % kLsBufs;
     const char* xbuf = smem + buf * kLsTileBytes;
     const char* ybuf = xbuf + 16 * kFragBytes;
 
-    if (wave == 0) ls_poll(up_count, kLsPollOff + (i & 3) * 256);
+    LS_STAMP(0);
     {
       const int want = i + kLsDist < n_my ? i + kLsDist + 1 : n_my;
       if (ready < want) wait_ready(want);  // uniform: `ready` comes from LDS words every wave reads after a barrier
-      issue_tile(i + kLsDist);
     }
+    // DMA of tile i + kLsDist: issued in 8 pieces between the MFMAs of phase A
+    const int nxt = i + kLsDist < n_my ? i + kLsDist : n_my - 1;
+    const int64_t tn = tile_of(nxt);
+    const unsigned ndst = (unsigned)(((i + kLsDist) % kLsBufs) * kLsTileBytes + wave * 4 * kFragBytes);
+    const char* nxb = job.save + (tn * kSaveTileSlots + x_slot0) * (int64_t)kFragBytes;
+    const char* nyb = job.gdump + (tn * kGradTileSlots + y_slot0) * (int64_t)kFragBytes;
+    auto dy_frag = [&](auto k_) -> bf16x8 {  // B operand of k-step ks as the producer stored it
+      constexpr int ks = decltype(k_)::value;
+      return bits_to_frag(*reinterpret_cast<const uint4*>(ybuf + ks * kFragBytes + ((ks & 1) ? lane_off1 : lane_off0)));
+    };
 
-    // (1) input gradient: dh[in rows of this wave][32 evaluations] = sum_k W^T[in][k] dy_l[k][eval]
-    f32x16 d0 = zero_acc(), d1 = zero_acc();
+    auto y_tr = [&](auto e_) -> bf16x8 {  // transposed dy operand of phase-B step e = 8 q + pos (rotated out tile, see below)
+      constexpr int e = decltype(e_)::value;
+      const int bb = ((e & 7) + 2 * wave) & 7;
+      return tr_frag(ybuf + 2 * bb * kFragBytes, lane, 0, e >> 3);
+    };
+    auto x_mask = [&](auto f_) -> uint4 {  // saved X_{l-1} fragment f of this wave's four = the ReLU mask of output fragment f
+      constexpr int f = decltype(f_)::value;
+      return *reinterpret_cast<const uint4*>(xbuf + (4 * wave + f) * kFragBytes + ((f & 1) ? lane_off1 : lane_off0));
+    };
+    // poll result of iteration i - kLsLag - 1: it landed before the barrier that closed iteration i - 1 (wave 0's counted
+    // wait), so every wave may read it now; it is looked at after this iteration's barrier (no LDS latency on that path)
+    const unsigned seen_word = i > kLsLag ? lds_u32(kLsPollOff + ((i - kLsLag - 1) & 3) * 256) : 0u;
+
+    LS_STAMP(1);
+    // ---- phase A: input gradient dh[in rows of this wave][32 evaluations] = sum_k W^T[in][k] dy_l[k][eval], 32 MFMAs, with
+    //      the B fragments read 3 k-steps ahead, the poll + 8 DMA pieces of the next tile issued between the MFMAs, and the
+    //      first operands of phase B read during the last k-steps ----
+    f32x16 d0, d1;
+    bf16x8 bq[3];
+    bf16x8 a0, a1, fq[3];
+    uint4 xm;
+    bq[0] = dy_frag(std::integral_constant<int, 0>{});
+    bq[1] = dy_frag(std::integral_constant<int, 1>{});
+    bq[2] = dy_frag(std::integral_constant<int, 2>{});
     static_for<16>([&](auto k_) {
       constexpr int ks = decltype(k_)::value;
-      const bf16x8 b = bits_to_frag(*reinterpret_cast<const uint4*>(ybuf + ks * kFragBytes + ((ks & 1) ? lane_off1 : lane_off0)));
-      d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[0][ks], b, d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[1][ks], b, d1, 0, 0, 0);
+      const bf16x8 b = bq[ks % 3];
+      if constexpr (ks == 0) {
+        mfma_vgpr_first(d0, wt[0][ks], b);
+        mfma_vgpr_first(d1, wt[1][ks], b);
+      } else {
+        mfma_vgpr(d0, wt[0][ks], b);
+        mfma_vgpr(d1, wt[1][ks], b);
+      }
+      if constexpr (ks + 3 < 16) bq[ks % 3] = dy_frag(std::integral_constant<int, ks + 3>{});
+      if constexpr (ks == 0) {
+        if (wave == 0) ls_poll(up_count, kLsPollOff + (i & 3) * 256);
+      }
+      if constexpr (ks >= 1 && ks <= 4) ls_dma16<(ks - 1) * kFragBytes, false>(nxb, dma_voff, ndst);
+      if constexpr (ks >= 5 && ks <= 8) ls_dma16<(ks - 5) * kFragBytes, true>(nyb, dma_voff, ndst + 16 * kFragBytes);
+      if constexpr (ks == 11) a0 = tr_frag(xbuf + (4 * wave) * kFragBytes, lane, 0, 0);
+      if constexpr (ks == 12) a1 = tr_frag(xbuf + (4 * wave + 2) * kFragBytes, lane, 0, 0);
+      if constexpr (ks == 13) fq[0] = y_tr(std::integral_constant<int, 0>{});
+      if constexpr (ks == 14) fq[1] = y_tr(std::integral_constant<int, 1>{});
+      if constexpr (ks == 15) {
+        fq[2] = y_tr(std::integral_constant<int, 2>{});
+        xm = x_mask(std::integral_constant<int, 0>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
     });
-    // (2) dy_{l-1} = dh o relu'(X_{l-1}): the saved activation fragment of the same slot is the mask; bf16, sc1 store
-    {
-      char* ob = job.gdump + tile_of(i) * kGradTileSlots * (int64_t)kFragBytes;
-      static_for<4>([&](auto f_) {
-        constexpr int f = decltype(f_)::value;  // fragment f = 2 a + s of this wave's four
-        constexpr int a = f >> 1, s = f & 1;
-        const uint4 xm = *reinterpret_cast<const uint4*>(xbuf + (4 * wave + f) * kFragBytes + (s ? lane_off1 : lane_off0));
-        bf16x8 fr;
-        if constexpr (a == 0) fr = acc_to_frag<s, false>(d0);
-        else fr = acc_to_frag<s, false>(d1);
-        const uint4 fb = frag_to_bits(fr);
-        u32x4 v = {fb.x & relu_pair_mask(xm.x), fb.y & relu_pair_mask(xm.y), fb.z & relu_pair_mask(xm.z),
-                   fb.w & relu_pair_mask(xm.w)};
-        ls_store16<f * kFragBytes, true>(ob, s ? st_voff1 : st_voff0, v);
-      });
-    }
-    // (3) weight gradient: dW[in rows of this wave][256 out] += X_{l-1}^T dy_l over the tile's 32 evaluations.  The wave
-    //     walks the out tiles in the rotated order b = (pos + 2 wave) mod 8, so that "its" two bias columns (out tiles
-    //     2 wave, 2 wave + 1) are always positions 0 and 1 and no branch depends on the wave; acc[a][pos] is out tile b.
+    LS_STAMP(2);
+    // ---- phase B: weight gradient dW[in rows of this wave][256 out] += X_{l-1}^T dy_l (32 MFMAs) with the epilogue of
+    //      phase A between them: dy_{l-1} = bf16(dh) o relu'(X_{l-1}) — the saved activation fragment of the same slot is
+    //      the mask — in 16 dword pieces, every finished fragment leaves by one sc1 store.  The wave walks the out tiles
+    //      in the rotated order b = (pos + 2 wave) mod 8, so that "its" two bias columns (out tiles 2 wave, 2 wave + 1)
+    //      are always positions 0 and 1 and no branch depends on the wave; acc[a][pos] is out tile b. ----
+    char* ob = job.gdump + tile_of(i) * kGradTileSlots * (int64_t)kFragBytes;
+    bf16x8 a0n, a1n;  // operands of the second half (evaluations 16..31), read a few steps ahead
+    u32x4 ov;
+    static_for<16>([&](auto e_) {
+      constexpr int e = decltype(e_)::value;
+      constexpr int pos = e & 7;
+      const bf16x8 bf = fq[e % 3];
+      acc[0][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf, acc[0][pos], 0, 0, 0);
+      acc[1][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc[1][pos], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // nothing of the epilogue below may move above these two MFMAs
+      if constexpr (e == 0) asm volatile("s_nop 7" ::: "memory");
+      if constexpr (e == 3) a0n = tr_frag(xbuf + (4 * wave) * kFragBytes, lane, 0, 1);
+      if constexpr (e == 4) a1n = tr_frag(xbuf + (4 * wave + 2) * kFragBytes, lane, 0, 1);
+      if constexpr (e == 7) {
+        LS_STAMP(3);
+        a0 = a0n;
+        a1 = a1n;
+      }
+      if constexpr (pos < 2) {  // bias column sums: 8 bf16 values of the dy operand through the bf16 dot product with ones
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const bf16x8 a0 = tr_frag(xbuf + (4 * wave) * kFragBytes, lane, 0, q);
-      const bf16x8 a1 = tr_frag(xbuf + (4 * wave + 2) * kFragBytes, lane, 0, q);
-      static_for<8>([&](auto b_) {
-        constexpr int pos = decltype(b_)::value;
-        const int b = (pos + 2 * wave) & 7;
-        const bf16x8 bf = tr_frag(ybuf + 2 * b * kFragBytes, lane, 0, q);
-        if constexpr (pos < 2) {
-          float sacc = 0.0f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) sacc += (float)bf[j];
-          bsum[pos] += sacc;
+        for (int j = 0; j < 4; ++j) {
+          const bf16x2 pr = {bf[2 * j], bf[2 * j + 1]};
+          bsum[pos] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, bsum[pos], false);
         }
-        acc[0][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf, acc[0][pos], 0, 0, 0);
-        acc[1][pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc[1][pos], 0, 0, 0);
-      });
-    }
+      }
+      if constexpr (e + 3 < 16) fq[e % 3] = y_tr(std::integral_constant<int, e + 3>{});
+      {  // epilogue piece e: dword w of output fragment f = 2 a + s
+        constexpr int f = e >> 2, w = e & 3, aa = f >> 1, sh = f & 1;
+        float lo, hi;
+        if constexpr (aa == 0) { lo = d0[8 * sh + 2 * w]; hi = d0[8 * sh + 2 * w + 1]; }
+        else { lo = d1[8 * sh + 2 * w]; hi = d1[8 * sh + 2 * w + 1]; }
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 pk = {(__bf16)lo, (__bf16)hi};
+        const unsigned xw = w == 0 ? xm.x : (w == 1 ? xm.y : (w == 2 ? xm.z : xm.w));
+        ov[w] = relu_gate_pair(__builtin_bit_cast(unsigned, pk), xw);
+        if constexpr (w == 3) {
+          ls_store16<f * kFragBytes, true>(ob, sh ? st_voff1 : st_voff0, ov);
+          if constexpr (f < 3) xm = x_mask(std::integral_constant<int, (f < 3 ? f + 1 : 3)>{});
+        }
+      }
+#ifdef LS_DMA_IN_B
+      if constexpr ((e & 1) == 0 && e < 8) ls_dma16<(e / 2) * kFragBytes, false>(nxb, dma_voff, ndst);
+      if constexpr ((e & 1) == 0 && e >= 8) ls_dma16<((e - 8) / 2) * kFragBytes, true>(nyb, dma_voff, ndst + 16 * kFragBytes);
+#endif
+#ifndef LS_NO_SB_B
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
 
+    LS_STAMP(4);
     // (4) retire: everything issued before the last kLsLag iterations is complete -> tile i + 1 is in LDS, the stores of
     //     tile i - kLsLag have reached memory, the poll of iteration i - kLsLag has landed
     if (wave == 0) ls_wait_vm<kLsLag * 14 - 1>(); else ls_wait_vm<kLsLag * 12>();
+    LS_STAMP(5);
     ls_barrier();
-    if (i >= kLsLag && stage != 0) {
-      const int seen = (int)lds_u32(kLsPollOff + ((i - kLsLag) & 3) * 256);
-      ready = seen > ready ? seen : ready;
-    }
+    LS_STAMP(6);
+    if (i > kLsLag && stage != 0) ready = (int)seen_word > ready ? (int)seen_word : ready;
     // tile i - kLsLag is published (every iteration issues the store, so that the counts above hold from the start)
     if (wave == 0) ls_flag_store(my_count, (unsigned)(i >= kLsLag ? i - kLsLag + 1 : 0));
   }
@@ -377,6 +485,14 @@ __global__ __launch_bounds__(kThreads) void nerf_bwd_head_kernel(
 }  // namespace lnrf
 
 using namespace lnrf;
+
+#ifdef LNRF_TIMELINE
+// debug library only (tools/build_timeline.sh): where the stamped workgroups write their s_memtime values
+extern "C" int lnrf_debug_set_ls_timeline(void* buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(lnrf::g_ls_timeline_buf), &buf, sizeof(buf));
+  return e == hipSuccess ? LNRF_OK : hip_fail(e, "hipMemcpyToSymbol(g_ls_timeline_buf)");
+}
+#endif
 
 static int ls_pipelines_for_device(int* out) {
   int dev = 0, cus = 0;

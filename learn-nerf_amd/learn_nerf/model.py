@@ -99,6 +99,29 @@ def ls_status(ctx) -> int:
     return int(buf[off:off + 4].view(torch.int32).item())
 
 
+def backward_ls_pair(ctx_a, g_density_a, g_rgb_a, grad_a, ctx_b, g_density_b, g_rgb_b, grad_b) -> None:
+    """The layer-stationary backward of TWO fused NeRFModel contexts (train.py:141-142: coarse and fine) in one persistent
+    launch (lnrf_nerf_mlp_bwd_ls2): the pipelines of the chip are shared in proportion to the evaluations, so the coarse
+    pass does not pay a pipeline fill and drain of its own.  grad_a / grad_b += d L / d params."""
+    shape = L.NerfShape(5, 4, 256, 128, 10, 4)
+    lib = L.lib()
+    dev = grad_a.device
+    la = _ws.lease("nerf_bwd_ls", lib.lnrf_nerf_bwd_ls_scratch_bytes(ctypes.byref(shape), ctx_a["m"]), dev)
+    lb = _ws.lease("nerf_bwd_ls", lib.lnrf_nerf_bwd_ls_scratch_bytes(ctypes.byref(shape), ctx_b["m"]), dev)
+    with _prof.section("bwd_ls"):
+        L.check(lib.lnrf_nerf_mlp_bwd_ls2(
+            ctypes.byref(shape),
+            L.ptr(ctx_a["packed"], torch.uint8), L.ptr(ctx_a["save"], torch.uint8), L.ptr(ctx_a["density"]),
+            L.ptr(ctx_a["rgb"]), L.ptr(g_density_a.reshape(-1)), L.ptr(g_rgb_a.reshape(-1, 3)), ctx_a["m"],
+            L.ptr(la.buf, torch.uint8), L.ptr(grad_a),
+            L.ptr(ctx_b["packed"], torch.uint8), L.ptr(ctx_b["save"], torch.uint8), L.ptr(ctx_b["density"]),
+            L.ptr(ctx_b["rgb"]), L.ptr(g_density_b.reshape(-1)), L.ptr(g_rgb_b.reshape(-1, 3)), ctx_b["m"],
+            L.ptr(lb.buf, torch.uint8), L.ptr(grad_b), L.stream()), "nerf_mlp_bwd_ls2")
+    ctx_a["ls_scratch"], ctx_b["ls_scratch"] = la.buf, lb.buf
+    la.release()
+    lb.release()
+
+
 def _is_leafy(d) -> bool:
     return any(isinstance(v, torch.Tensor) for v in d.values())
 

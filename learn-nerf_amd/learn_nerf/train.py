@@ -195,11 +195,15 @@ class TrainLoop:
         out_scale = 2.0 * inv  # d mean((out-t)^2) / d out
         gc, gf, gbg = self._slices(grad_flat) if want_grad else (None, None, None)
 
-        def backward_of(ts, dens, rgb, out, model, ctx, gslice, names, auxs):
+        def output_grads(ts, dens, rgb, out, names, auxs):
             gw = [self.loss_weights[k] / n for k in names]
             gd, grgb, gaux = ops.composite_bwd(ts, t_min, t_max, mask, dens, rgb, bg, gbg, outputs=out,
                                                targets=targets, out_scale=out_scale, aux=auxs, g_aux_w=gw)
             g_aux = {k: gaux[..., i] for i, k in enumerate(names)} if names else None
+            return gd, grgb, g_aux
+
+        def backward_of(ts, dens, rgb, out, model, ctx, gslice, names, auxs):
+            gd, grgb, g_aux = output_grads(ts, dens, rgb, out, names, auxs)
             model.backward(ctx, gd, grgb, g_aux, gslice)
 
         coarse_args = (ts_c, dens_c, rgb_c, out_c, self.coarse, ctx_c, gc, names_c, auxs_c)
@@ -229,7 +233,14 @@ class TrainLoop:
                 for i, k in enumerate(names):
                     loss_dict[f"{prefix}_{k}"] = means[i]  # train.py:146-151
 
-        if want_grad:
+        if want_grad and coarse_done is None and _ls_pair(self.coarse, ctx_c, self.fine, ctx_f):
+            # both models are fused NeRFModels on the layer-stationary backward: one persistent launch for the two
+            from .model import backward_ls_pair
+
+            gd_c, grgb_c, _ = output_grads(ts_c, dens_c, rgb_c, out_c, names_c, auxs_c)
+            gd_f, grgb_f, _ = output_grads(ts_f, dens_f, rgb_f, out_f, names_f, auxs_f)
+            backward_ls_pair(ctx_c, gd_c, grgb_c, gc, ctx_f, gd_f, grgb_f, gf)
+        elif want_grad:
             if coarse_done is None:
                 backward_of(*coarse_args)
                 if self.density_penalty is None:
@@ -311,6 +322,14 @@ class TrainLoop:
 
     def average_density(self, key, model, params, bbox_min, bbox_max) -> torch.Tensor:
         return self._average_density(key, model, model.flat(params), _vec3(bbox_min), _vec3(bbox_max), None)
+
+
+def _ls_pair(coarse, ctx_c, fine, ctx_f) -> bool:
+    """Both contexts come from fused NeRFModels that ask for the layer-stationary backward and hold evaluations."""
+    from .model import NeRFModel
+
+    return all(type(mdl) is NeRFModel and mdl.backward_kernel == "ls" and isinstance(ctx, dict)
+               and ctx.get("kind") == "fused" and ctx["m"] > 0 for mdl, ctx in ((coarse, ctx_c), (fine, ctx_f)))
 
 
 def apply_gradients(flat, grad, opt_m, opt_v, step: int, lr: float, b1: float, b2: float, eps: float,

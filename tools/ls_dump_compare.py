@@ -1,0 +1,48 @@
+"""Debug aid: run the chain launch and the layer-stationary backward on the same inputs and compare their gradient dumps
+slot range by slot range (dy11, dy10m, dy8 ... dy0), then the gradients per Dense layer.  python tools/ls_dump_compare.py [m]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "learn-nerf_amd")); sys.path.insert(0, ROOT)
+import torch
+from learn_nerf import _lib as L
+from learn_nerf.model import NeRFModel
+
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+lib = L.lib()
+gen = torch.Generator().manual_seed(0)
+x = (torch.rand(m, 3, generator=gen) * 2 - 1).cuda()
+d = torch.randn(m, 3, generator=gen); d = (d / d.norm(dim=-1, keepdim=True)).cuda()
+gd = torch.randn(m, generator=gen).cuda(); gr = torch.randn(m, 3, generator=gen).cuda()
+model = NeRFModel()
+flat = model.flat(model.init(dict(params=1))["params"])
+dens, rgb, _, ctx = model.forward_points(flat, x, d, save=True)
+shape = model._shape_struct()
+n_tiles = ((m + 31) // 32 + 7) // 8 * 8
+sa = torch.zeros(lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device="cuda")
+sb = torch.zeros(lib.lnrf_nerf_bwd_ls_scratch_bytes(ctypes.byref(shape), m), dtype=torch.uint8, device="cuda")
+ga, gb = torch.zeros_like(flat), torch.zeros_like(flat)
+args = (ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8), L.ptr(ctx["density"]),
+        L.ptr(ctx["rgb"]), L.ptr(gd), L.ptr(gr), m)
+L.check(lib.lnrf_nerf_mlp_bwd(*args, L.ptr(sa, torch.uint8), L.ptr(ga), L.stream()), "bwd")
+L.check(lib.lnrf_nerf_mlp_bwd_ls(*args, L.ptr(sb, torch.uint8), L.ptr(gb), L.stream()), "bwd_ls")
+torch.cuda.synchronize()
+da = sa[:156 * n_tiles * 1024].view(n_tiles, 156, 1024).view(torch.int16)
+db = sb[:156 * n_tiles * 1024].view(n_tiles, 156, 1024).view(torch.int16)
+names = [("dy11", 0, 2), ("dy10m", 2, 12)] + [(f"dy{8 - k}", 12 + 16 * k, 28 + 16 * k) for k in range(9)]
+for name, s0, s1 in names:
+    a, b = da[:, s0:s1], db[:, s0:s1]
+    bad = (a != b)
+    nb = int(bad.sum())
+    msg = ""
+    if nb:
+        t, s, e = [int(v[0]) for v in torch.nonzero(bad, as_tuple=True)]
+        tiles_bad = bad.flatten(1).any(1).nonzero().flatten()[:8].tolist()
+        slots_bad = bad.any(0).any(1).nonzero().flatten()[:16].tolist()
+        msg = f" first (tile {t}, slot {s0 + s}, elem {e}); tiles {tiles_bad}; slots {[s0 + v for v in slots_bad]}"
+    print(f"{name}: {nb} of {a.numel()} bf16 words differ{msg}")
+off = 0
+for i, (fi, fo) in enumerate(model.layer_dims()):
+    for nm, n in (("kernel", fi * fo), ("bias", fo)):
+        a, b = gb[off:off + n], ga[off:off + n]
+        print(f"Dense_{i}.{nm}: rel {float((a - b).norm() / b.norm().clamp_min(1e-30)):.3e} nan {int(torch.isnan(a).sum())}")
+        off += n
