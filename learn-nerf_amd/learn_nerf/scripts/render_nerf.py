@@ -36,6 +36,11 @@ def argparser() -> argparse.ArgumentParser:
     return parser
 
 
+def quantise(colors: np.ndarray) -> np.ndarray:
+    """Colours in [-1, 1] -> uint8 by TRUNCATION, no rounding and no clip (reference scripts/render_nerf.py:93-96)."""
+    return ((colors + 1) * 127.5).astype(np.uint8)
+
+
 class RenderSession:
     """Loads a checkpoint once, renders any number of camera views, then writes them into one PNG."""
 
@@ -65,7 +70,7 @@ class RenderSession:
             self.key, slice_key = self.key.split(2)
             pieces.append(self.render_fn(slice_key, rays[start:start + step].contiguous()))
         colors = torch.cat(pieces, dim=0).cpu().numpy().reshape(height, width, 3)
-        self.images.append(((colors + 1) * 127.5).astype(np.uint8))
+        self.images.append(quantise(colors))
 
     def save(self, output_path: str):
         from PIL import Image

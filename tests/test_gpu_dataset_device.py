@@ -1,8 +1,9 @@
 """
 SURVEY.md section 8 row f1 on the GPU: ray generation (CameraView.bare_rays, dataset.py:52-78) by the HIP kernel
 lnrf_camera_rays and the shuffled batch iterator (ShuffledDataset.iterate_batches, dataset.py:222-240) with the
-shards resident in HBM and batches assembled by lnrf_gather_rows.  The checker is the package's NumPy host path
-(itself covered on the CPU by tests/test_abi_and_host.py against the reference's test_dataset.py invariants).
+shards resident in HBM and batches assembled by lnrf_gather_rows.  Ray generation is checked against oracle/dataset.py
+(the CPU restatement of dataset.py:52-78, pinned in tests/test_dataset_oracle.py); the iterator against the host iterator
+(bit-identical) and against the invariants of the reference's own test (learn_nerf/test_dataset.py:49-81).
 """
 import numpy as np
 import pytest
@@ -14,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("width,height", [(1, 1), (1, 7), (9, 1), (33, 17), (400, 400)])
-def test_camera_rays_kernel_matches_numpy(width, height):
+def test_camera_rays_kernel_matches_oracle(width, height):
     from learn_nerf.dataset import CameraView
+    from oracle import dataset as OD
 
     z = np.array([0.3, -0.5, 0.81])
     z /= np.linalg.norm(z)
@@ -24,12 +26,12 @@ def test_camera_rays_kernel_matches_numpy(width, height):
     y = np.cross(z, x)
     view = CameraView(camera_direction=tuple(z), camera_origin=(1.5, -2.0, 0.7), x_axis=tuple(x), y_axis=tuple(y),
                       x_fov=0.69, y_fov=0.43)
-    host = view.bare_rays(width, height)
+    host = torch.from_numpy(OD.bare_rays(tuple(z), (1.5, -2.0, 0.7), tuple(x), tuple(y), 0.69, 0.43, width, height))
     dev = view.bare_rays(width, height, device="cuda")
     assert dev.is_cuda and dev.shape == host.shape == (width * height, 2, 3) and dev.dtype == torch.float32
     assert torch.equal(dev[:, 0].cpu(), host[:, 0])  # origins are copied
     err = (dev[:, 1].cpu() - host[:, 1]).abs().max().item()
-    print(f"{width}x{height}: max |dir - numpy| = {err:.2e}")
+    print(f"{width}x{height}: max |dir - oracle| = {err:.2e}")
     assert err < 1e-6  # raster order, end-point-inclusive linspace, W = 1 / H = 1 -> -1
     assert (dev[:, 1].norm(dim=-1) - 1).abs().max().item() < 1e-6
 

@@ -13,6 +13,8 @@ import sys
 import numpy as np
 import pytest
 
+from oracle import dataset as OD
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "learn-nerf_amd")
@@ -72,7 +74,7 @@ def test_train_resume_render(tmp_path, coarse, fine, batch, steps, min_psnr):
     refs = []
     for name in ("0000.png", "0001.png"):
         rgba = np.array(Image.open(os.path.join(data, name)).convert("RGBA")).astype(np.float64)
-        refs.append(np.round(rgba[..., :3] * (rgba[..., 3:] / 255)).astype(np.uint8))  # dataset.py:108-111
+        refs.append(OD.premultiply_alpha(rgba.astype(np.uint8)))  # oracle restatement of dataset.py:108-111
     ref = np.concatenate(refs, axis=1)
     # background was trained from (-1,-1,-1); empty pixels in the data are black too
     p = psnr(img, ref)
