@@ -137,6 +137,12 @@ __device__ __forceinline__ unsigned relu_gate_pair(unsigned pk, unsigned x) {
 // results back one register at a time.  Exactly-same-register accumulate chains need no software wait states; the first
 // VALU read of a result is placed (scheduling fences) behind two later MFMAs, i.e. after the producing MFMA has left the
 // pipe, plus an explicit s_nop.
+// bias column sum: acc += the two bf16 halves of `pair` (dot product with (1, 1)); asm volatile keeps it between the MFMAs
+// where it is written (the compiler sinks the builtin below the tile barrier, where nothing overlaps it)
+__device__ __forceinline__ void dot2_ones(float& acc, unsigned pair) {
+  const unsigned ones = 0x3f803f80u;
+  asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(pair), "v"(ones));
+}
 __device__ __forceinline__ void mfma_vgpr_first(f32x16& d, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
 }
@@ -345,13 +351,11 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
         a1 = a1n;
       }
       if constexpr (pos < 2) {  // bias column sums: 8 bf16 values of the dy operand through the bf16 dot product with ones
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x2 pr = {bf[2 * j], bf[2 * j + 1]};
-          bsum[pos] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, bsum[pos], false);
-        }
+        const uint4 bw = frag_to_bits(bf);
+        dot2_ones(bsum[pos], bw.x);
+        dot2_ones(bsum[pos], bw.y);
+        dot2_ones(bsum[pos], bw.z);
+        dot2_ones(bsum[pos], bw.w);
       }
       if constexpr (e + 3 < 16) fq[e % 3] = y_tr(std::integral_constant<int, e + 3>{});
       {  // epilogue piece e: dword w of output fragment f = 2 a + s

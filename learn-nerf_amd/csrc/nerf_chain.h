@@ -69,7 +69,7 @@ __device__ __forceinline__ void bwd_chain_tile(RING& ring, SINK& sink, const cha
   // ReLU masks of h0..h7 and h10 (written by the forward), 16 bytes per lane and layer
   uint4 relu_mask[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
+  for (int i = HEAD_ONLY ? 8 : 0; i < 9; ++i)  // the head launch only applies relu'(h10)
     relu_mask[i] = *reinterpret_cast<const uint4*>(save + dump_off(kSaveMask + i, tile, save_tiles, kSaveTileSlots) +
                                                    lane * 16);
   __syncthreads();

@@ -153,8 +153,9 @@ class NeRFModel(ModelBase):
     precision: str = "bf16"  # "bf16" (fused MFMA) | "fp32" (exact dense path)
     render_precision: str = "bf16x3"  # fused path, forward without backward: "bf16x3" (split) | "bf16"
     # fused path, backward: "ls" = layer-stationary pipeline (lnrf_nerf_mlp_bwd_ls: one CU per Dense layer, dW in
-    # registers) | "split" = separate chain and weight-gradient launches through HBM (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
-    backward_kernel: str = "split"
+    # registers; measured 4.74 vs 5.11 ms per 4096-ray step) | "split" = separate chain and weight-gradient launches through
+    # HBM (lnrf_nerf_mlp_bwd_chain / _bwd_weights)
+    backward_kernel: str = "ls"
     tag: str = "mlp"  # label used by the optional kernel-family timers (_prof)
     # TrainLoop may run the coarse backward on a second stream beside the fine forward; for this model every kernel
     # already fills all 256 CUs at one workgroup per CU, so the two streams only time-slice (5.012 / 5.020 ms without,
