@@ -133,6 +133,17 @@ int lnrf_composite_bwd(const float* ts, const float* t_min, const float* t_max,
                        float* g_density, float* g_rgb, float* g_aux, float* g_background,
                        lnrf_stream_t stream);
 
+/* The same, with the background gradient (the one sum over rays this call forms, render.py:170-176) added in a fixed
+ * order: per-workgroup partial sums in `scratch` (lnrf_composite_bwd_scratch_bytes(n_rays) bytes, 16-byte aligned), folded
+ * by a second launch — bit-reproducible, where lnrf_composite_bwd lets the workgroups meet in fp32 atomics. */
+int64_t lnrf_composite_bwd_scratch_bytes(int64_t n_rays);
+int lnrf_composite_bwd_det(const float* ts, const float* t_min, const float* t_max, const uint8_t* mask,
+                           const float* density, const float* rgb, const float* aux, int32_t n_aux,
+                           const float* background, int64_t n_rays, int32_t t, const float* g_out, const float* outputs,
+                           const float* targets, int64_t target_stride, float out_scale, const float* g_aux_w,
+                           float* g_density, float* g_rgb, float* g_aux, float* g_background, void* scratch,
+                           int64_t scratch_bytes, lnrf_stream_t stream);
+
 /* ----------------------------------------------------------- generic dense ---- */
 
 /* sinusoidal_emb (model.py:65-77): out[m, col_off + c*2F + {f | F+f}] = sin|cos(2^f x[m,c]).
@@ -183,6 +194,15 @@ int lnrf_dense_fwd_gated(const float* x, int64_t ldx, const float* w, const floa
 int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gw,
                           float* gb, int64_t m, int32_t k, int32_t n, lnrf_stream_t stream);
 
+/* The same with a FIXED summation order (bit-reproducible): the splits of the reduction over m leave their partial
+ * sums in `scratch` (lnrf_dense_bwd_weight_scratch_bytes(m, k, n) bytes; k = 0 when x / gw are null) and a second launch
+ * adds them in order, instead of fp32 atomics whose arrival order changes from run to run.  What the package's exact-fp32
+ * path uses (reference: jax.grad through nn.Dense, model.py:51-60, is deterministic on one device). */
+int64_t lnrf_dense_bwd_weight_scratch_bytes(int64_t m, int32_t k, int32_t n);
+int lnrf_dense_bwd_weight_det(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gw, float* gb,
+                              int64_t m, int32_t k, int32_t n, void* scratch, int64_t scratch_bytes,
+                              lnrf_stream_t stream);
+
 /* General strided fp32 GEMM on the f32 MFMA behind the dense entry points above:
  *   C[i*ldc + j] (op)= sum_r A[i*sa_i + r*sa_r] * B[r*sb_r + j*sb_j],  i < I, j < J, r < R
  * mode 0: C = act(sum + bias[j]);  1: C += sum;  2: atomic C += sum with the reduction split over
@@ -191,6 +211,14 @@ int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t 
 int lnrf_gemm_f32(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r, int64_t sb_j,
                   float* c, int64_t ldc, const float* bias, int32_t act, int32_t mode, int64_t i_rows,
                   int32_t j_cols, int64_t r_depth, int32_t splits, lnrf_stream_t stream);
+
+/* lnrf_gemm_f32 mode 2 (C += A B, reduction split over workgroups) with a FIXED summation order: C has contiguous
+ * rows (ldc == J); the splits leave their partial tiles in `scratch` (lnrf_gemm_f32_det_scratch_bytes bytes) and a
+ * second launch adds them in order — bit-reproducible, unlike the atomic form. */
+int64_t lnrf_gemm_f32_det_scratch_bytes(int64_t i_rows, int32_t j_cols, int64_t r_depth);
+int lnrf_gemm_f32_det(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r, int64_t sb_j, float* c,
+                      int64_t i_rows, int32_t j_cols, int64_t r_depth, void* scratch, int64_t scratch_bytes,
+                      lnrf_stream_t stream);
 
 /* --------------------------------------------------- hash-grid encoding ---- */
 

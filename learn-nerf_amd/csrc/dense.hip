@@ -54,7 +54,9 @@ struct Gate {
 
 // C[i][j] (op)= sum_r A(i,r) * B(r,j),  A(i,r) = a[i*sa_i + r*sa_r],  B(r,j) = b[r*sb_r + j*sb_j].
 // One workgroup = 64x64 output tile, 4 waves in a 2x2 grid of 32x32 MFMA tiles.
-// mode 0: store act(C + bias);  1: C += result (plain);  2: atomicAdd (split reduction).
+// mode 0: store act(C + bias);  1: C += result (plain);  2: atomicAdd (split reduction);
+// mode 3: split reduction without atomics — split z stores its partial tile at c[(z * I + row) * ldc + col] and
+// dense_fold_kernel adds the splits in a fixed order (lnrf_dense_bwd_weight_det).
 // BF16 = false: exact fp32 products (v_mfma_f32_32x32x2_f32).  BF16 = true: operands rounded to bf16 while they
 // are staged into LDS, one v_mfma_f32_32x32x16_bf16 per 16-deep chunk, fp32 accumulate / bias / activation:
 // the arithmetic of the fused kernels for models that have no fused kernel (16x the MFMA rate; the kernel is
@@ -156,10 +158,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int q = 0; q < 16; ++q) {
       const int64_t row = i0 + wr * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
       if (row < I) {
-        float* dst = c + row * ldc + col;
+        float* dst = c + (mode == 3 ? (int64_t)blockIdx.z * I + row : row) * ldc + col;
         const float gm = (gate.y && col < gate.n) ? act_grad_from_output(gate.y[row * gate.ld + col], gate.act) : 1.0f;
         if (mode == 0) *dst = act_apply(acc[q] + bv, act) * gm;
         else if (mode == 1) *dst += acc[q] * gm;
+        else if (mode == 3) *dst = acc[q];
         else atomicAdd(dst, acc[q]);
       }
     }
@@ -359,10 +362,11 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const float* __restrict__
       for (int q = 0; q < 16; ++q) {
         const int64_t row = i0 + wr * 64 + x * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
         if (row < I) {
-          float* dst = c + row * ldc + col;
+          float* dst = c + (mode == 3 ? (int64_t)blockIdx.z * I + row : row) * ldc + col;
           const float gm = (gate.y && col < gate.n) ? act_grad_from_output(gate.y[row * gate.ld + col], gate.act) : 1.0f;
           if (mode == 0) *dst = act_apply(acc[x][y][q] + bvv, act) * gm;
           else if (mode == 1) *dst += acc[x][y][q] * gm;
+          else if (mode == 3) *dst = acc[x][y][q];
           else atomicAdd(dst, acc[x][y][q]);
         }
       }
@@ -413,6 +417,34 @@ __global__ __launch_bounds__(256) void col_sum4_kernel(const float* __restrict__
   }
 }
 
+// out[e] += parts[0][e] + parts[1][e] + ... in that order (e < count): the deterministic end of a split reduction
+__global__ __launch_bounds__(256) void dense_fold_kernel(const float* __restrict__ parts, int n_parts, int64_t count,
+                                                         float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  float s = 0.0f;
+  for (int p = 0; p < n_parts; ++p) s += parts[(int64_t)p * count + e];
+  out[e] += s;
+}
+// parts[block][j] = sum of the block's 512 rows of g[:, j] (any n, any alignment); folded by dense_fold_kernel
+__global__ __launch_bounds__(256) void col_sum_parts_kernel(const float* __restrict__ g, int64_t ldg, int64_t m, int n,
+                                                            float* __restrict__ parts) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * kColSumRows;
+  const int64_t i1 = i0 + kColSumRows < m ? i0 + kColSumRows : m;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + cl;
+    float s = 0.0f;
+    if (j < n)
+      for (int64_t i = i0 + rl; i < i1; i += 4) s += g[i * ldg + j];
+    part[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && j < n) parts[(int64_t)blockIdx.x * n + j] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+    __syncthreads();
+  }
+}
+
 __global__ void act_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y,
                                int64_t ldy, int act, int64_t m, int n) {
   const int64_t total = m * n;
@@ -452,7 +484,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r,
                        int64_t sb_j, float* c, int64_t ldc, const float* bias, int act, int mode,
                        int64_t I, int J, int64_t R, int splits, hipStream_t stream,
-                       Gate gate = Gate{nullptr, 0, 0, 0}) {
+                       Gate gate = Gate{nullptr, 0, 0, 0}, int* splits_used = nullptr) {
+  if (splits_used) *splits_used = 0;
   if (I == 0 || J == 0) return LNRF_OK;
   if (splits < 1) splits = 1;
   // vectorised 128x128 kernel: both operands contiguous along one of their dimensions, 16-byte aligned rows,
@@ -472,6 +505,7 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
     if (per % 4 != 0) per = ((per + 3) / 4) * 4;
     int nsplit = (int)((R + per - 1) / per);
     if (nsplit < 1) nsplit = 1;
+    if (splits_used) *splits_used = nsplit;
     const int64_t ni = (I + BI - 1) / BI, njt = (J + BJ - 1) / BJ;
     dim3 grid((unsigned)((ni >= 64 ? ((ni + 7) / 8) * 8 : ni) * njt), 1u, (unsigned)nsplit);  // tile order: see the kernel
 #define LNRF_BIG(BF, AR, BR)                                                                                          \
@@ -501,6 +535,7 @@ static int launch_gemm(const float* a, int64_t sa_i, int64_t sa_r, const float* 
   if (per < RC) per = RC;
   splits = (int)((R + per - 1) / per);
   if (splits < 1) splits = 1;
+  if (splits_used) *splits_used = splits;
   dim3 grid((unsigned)((I + TI - 1) / TI), (unsigned)((J + TJ - 1) / TJ), (unsigned)splits);
   if (g_dense_bf16)
     hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, stream, a, sa_i, sa_r, b, sb_r, sb_j, c, ldc,
@@ -600,6 +635,52 @@ extern "C" int lnrf_dense_bwd_weight(const float* x, int64_t ldx, const float* g
   return LNRF_OK;
 }
 
+static int wgrad_splits(int64_t m, int k, int n) {
+  const int tiles = ((k + TI - 1) / TI) * ((n + TJ - 1) / TJ);
+  int splits = (int)((2048 + tiles - 1) / tiles);
+  if (splits > 512) splits = 512;
+  const int64_t max_splits = (m + 255) / 256;
+  if (splits > max_splits) splits = (int)max_splits;
+  return splits < 1 ? 1 : splits;
+}
+extern "C" int64_t lnrf_dense_bwd_weight_scratch_bytes(int64_t m, int32_t k, int32_t n) {
+  if (m < 0 || k < 0 || n < 1) return -1;
+  const int64_t kernel_parts = k > 0 ? (int64_t)wgrad_splits(m, k, n) * k * n : 0;
+  const int64_t bias_parts = (m + kColSumRows - 1) / kColSumRows * n;
+  return (kernel_parts + bias_parts) * (int64_t)sizeof(float) + 256;
+}
+
+// lnrf_dense_bwd_weight with a fixed summation order: every split of the reduction over m stores its partial sums in
+// `scratch` and a second launch adds them split by split, so two calls on the same inputs agree bit for bit.
+extern "C" int lnrf_dense_bwd_weight_det(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gw, float* gb,
+                                         int64_t m, int32_t k, int32_t n, void* scratch, int64_t scratch_bytes,
+                                         lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(gy && ((x && gw) || (!x && !gw && gb)), "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && n >= 1 && ldgy >= n && (!x || (k >= 1 && ldx >= k)), "bad sizes");
+  if (m == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(scratch && scratch_bytes >= lnrf_dense_bwd_weight_scratch_bytes(m, x ? k : 0, n), "scratch too small");
+  float* parts = reinterpret_cast<float*>(scratch);
+  hipStream_t st = as_stream(stream);
+  if (x) {
+    int used = 0;
+    int rc = launch_gemm(x, 1, ldx, gy, ldgy, 1, parts, n, nullptr, 0, 3, k, n, m, wgrad_splits(m, k, n), st,
+                         Gate{nullptr, 0, 0, 0}, &used);
+    if (rc != LNRF_OK) return rc;
+    const int64_t count = (int64_t)k * n;
+    hipLaunchKernelGGL(dense_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, parts, used, count, gw);
+    LNRF_LAUNCH_CHECK();
+    parts += (int64_t)wgrad_splits(m, k, n) * count;
+  }
+  if (gb) {
+    const int blocks = (int)((m + kColSumRows - 1) / kColSumRows);
+    hipLaunchKernelGGL(col_sum_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gy, ldgy, m, n, parts);
+    LNRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dense_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, parts, blocks, (int64_t)n, gb);
+    LNRF_LAUNCH_CHECK();
+  }
+  return LNRF_OK;
+}
+
 extern "C" int lnrf_sinusoidal_emb(const float* x, int64_t ldx, int64_t m, int32_t dims,
                                    int32_t freqs, float* out, int64_t ldo, int64_t col_off,
                                    lnrf_stream_t stream) {
@@ -632,4 +713,37 @@ extern "C" int lnrf_gemm_f32(const float* a, int64_t sa_i, int64_t sa_r, const f
   }
   return launch_gemm(a, sa_i, sa_r, b, sb_r, sb_j, c, ldc, bias, act, mode, i_rows, j_cols, r_depth, splits,
                      as_stream(stream));
+}
+
+// lnrf_gemm_f32 mode 2 with a fixed summation order: C (contiguous rows, ldc == J) += sum over r, the splits of the
+// reduction leaving their partial tiles in `scratch` (lnrf_gemm_f32_det_scratch_bytes) and added in order.
+static int gemm_det_splits(int64_t I, int J, int64_t R) {
+  const int64_t tiles = ((I + TI - 1) / TI) * ((J + TJ - 1) / TJ);
+  int64_t splits = (2048 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  if (splits > 512) splits = 512;
+  const int64_t max_splits = (R + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  return splits < 1 ? 1 : (int)splits;
+}
+extern "C" int64_t lnrf_gemm_f32_det_scratch_bytes(int64_t i_rows, int32_t j_cols, int64_t r_depth) {
+  if (i_rows < 0 || j_cols < 0 || r_depth < 0) return -1;
+  return (int64_t)gemm_det_splits(i_rows, j_cols, r_depth) * i_rows * j_cols * (int64_t)sizeof(float) + 256;
+}
+extern "C" int lnrf_gemm_f32_det(const float* a, int64_t sa_i, int64_t sa_r, const float* b, int64_t sb_r, int64_t sb_j,
+                                 float* c, int64_t i_rows, int32_t j_cols, int64_t r_depth, void* scratch,
+                                 int64_t scratch_bytes, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(a && b && c, "null pointer");
+  LNRF_CHECK_ARG(i_rows >= 0 && j_cols >= 0 && r_depth >= 0, "bad sizes");
+  if (i_rows == 0 || j_cols == 0 || r_depth == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(scratch && scratch_bytes >= lnrf_gemm_f32_det_scratch_bytes(i_rows, j_cols, r_depth), "scratch too small");
+  float* parts = reinterpret_cast<float*>(scratch);
+  int used = 0;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_gemm(a, sa_i, sa_r, b, sb_r, sb_j, parts, j_cols, nullptr, 0, 3, i_rows, j_cols, r_depth,
+                       gemm_det_splits(i_rows, j_cols, r_depth), st, Gate{nullptr, 0, 0, 0}, &used);
+  if (rc != LNRF_OK) return rc;
+  const int64_t count = i_rows * (int64_t)j_cols;
+  hipLaunchKernelGGL(dense_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, parts, used, count, c);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
 }

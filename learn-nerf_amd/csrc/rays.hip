@@ -251,7 +251,8 @@ __global__ void composite_bwd_kernel(const float* __restrict__ ts, const float* 
                                      const float* __restrict__ targets, int64_t target_stride,
                                      float out_scale, float gw0, float gw1, float gw2, float gw3,
                                      float* __restrict__ g_density, float* __restrict__ g_rgb,
-                                     float* __restrict__ g_aux, float* __restrict__ g_background) {
+                                     float* __restrict__ g_aux, float* __restrict__ g_background,
+                                     float* __restrict__ bg_parts) {
   __shared__ float s_bg[16][3];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -345,9 +346,35 @@ __global__ void composite_bwd_kernel(const float* __restrict__ ts, const float* 
     if (threadIdx.x < 3) {
       float s = 0.0f;
       for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_bg[w][threadIdx.x];
-      atomicAdd(g_background + threadIdx.x, s);
+      // bg_parts: the block's partial sum goes to its own row and composite_bg_fold_kernel adds the rows in a fixed order
+      // (bit-reproducible); without it the blocks meet in fp32 atomics
+      if (bg_parts) bg_parts[(int64_t)blockIdx.x * 4 + threadIdx.x] = s;
+      else atomicAdd(g_background + threadIdx.x, s);
     }
   }
+}
+
+// g_background[c] += sum over blocks of parts[block][c], c < 3: thread t adds the rows t, t + 256, ... in order, then the
+// 256 partial sums meet in a fixed binary tree
+__global__ __launch_bounds__(256) void composite_bg_fold_kernel(const float* __restrict__ parts, int n_blocks,
+                                                                float* __restrict__ g_background) {
+  __shared__ float red[256][3];
+  float s[3] = {0.0f, 0.0f, 0.0f};
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(parts + (int64_t)b * 4);
+    s[0] += v.x; s[1] += v.y; s[2] += v.z;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) red[threadIdx.x][c] = s[c];
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if ((int)threadIdx.x < half) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) red[threadIdx.x][c] += red[threadIdx.x + half][c];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) g_background[threadIdx.x] += red[0][threadIdx.x];
 }
 
 // fine_sampling (render.py:211-257). One wave per ray; LDS per wave: xs[tc+1], ys[tc+1],
@@ -613,14 +640,14 @@ extern "C" int lnrf_composite_fwd(const float* rays, int64_t ray_stride, const f
   return LNRF_OK;
 }
 
-extern "C" int lnrf_composite_bwd(const float* ts, const float* t_min, const float* t_max,
+static int composite_bwd_impl(const float* ts, const float* t_min, const float* t_max,
                                   const uint8_t* mask, const float* density, const float* rgb,
                                   const float* aux, int32_t n_aux, const float* background,
                                   int64_t n_rays, int32_t t, const float* g_out,
                                   const float* outputs, const float* targets,
                                   int64_t target_stride, float out_scale, const float* g_aux_w,
                                   float* g_density, float* g_rgb, float* g_aux,
-                                  float* g_background, lnrf_stream_t stream) {
+                                  float* g_background, float* bg_parts, lnrf_stream_t stream) {
   if (n_rays == 0) return LNRF_OK;
   LNRF_CHECK_ARG(ts && t_min && t_max && mask && density && rgb && background, "null pointer");
   LNRF_CHECK_ARG(g_density && g_rgb, "null gradient outputs");
@@ -634,9 +661,50 @@ extern "C" int lnrf_composite_bwd(const float* ts, const float* t_min, const flo
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n_rays + wpb - 1) / wpb)),
                      dim3(wpb * 64), 0, as_stream(stream), ts, t_min, t_max, mask, density, rgb, aux,
                      n_aux, background, n_rays, t, g_out, outputs, targets, target_stride, out_scale,
-                     gw[0], gw[1], gw[2], gw[3], g_density, g_rgb, g_aux, g_background);
+                     gw[0], gw[1], gw[2], gw[3], g_density, g_rgb, g_aux, g_background,
+                     g_background ? bg_parts : nullptr);
   LNRF_LAUNCH_CHECK();
+  if (g_background && bg_parts) {
+    hipLaunchKernelGGL(composite_bg_fold_kernel, dim3(1), dim3(256), 0, as_stream(stream), bg_parts,
+                       (int)((n_rays + wpb - 1) / wpb), g_background);
+    LNRF_LAUNCH_CHECK();
+  }
   return LNRF_OK;
+}
+
+extern "C" int lnrf_composite_bwd(const float* ts, const float* t_min, const float* t_max,
+                                  const uint8_t* mask, const float* density, const float* rgb,
+                                  const float* aux, int32_t n_aux, const float* background,
+                                  int64_t n_rays, int32_t t, const float* g_out,
+                                  const float* outputs, const float* targets,
+                                  int64_t target_stride, float out_scale, const float* g_aux_w,
+                                  float* g_density, float* g_rgb, float* g_aux,
+                                  float* g_background, lnrf_stream_t stream) {
+  return composite_bwd_impl(ts, t_min, t_max, mask, density, rgb, aux, n_aux, background, n_rays, t, g_out, outputs,
+                            targets, target_stride, out_scale, g_aux_w, g_density, g_rgb, g_aux, g_background, nullptr,
+                            stream);
+}
+
+extern "C" int64_t lnrf_composite_bwd_scratch_bytes(int64_t n_rays) {
+  return n_rays < 0 ? -1 : ((n_rays + 3) / 4) * 4 * (int64_t)sizeof(float) + 16;
+}
+
+// lnrf_composite_bwd with a fixed summation order for the background gradient (the only sum over rays the call forms):
+// per-workgroup partial sums in `scratch`, folded by a second launch.
+extern "C" int lnrf_composite_bwd_det(const float* ts, const float* t_min, const float* t_max,
+                                      const uint8_t* mask, const float* density, const float* rgb,
+                                      const float* aux, int32_t n_aux, const float* background,
+                                      int64_t n_rays, int32_t t, const float* g_out,
+                                      const float* outputs, const float* targets,
+                                      int64_t target_stride, float out_scale, const float* g_aux_w,
+                                      float* g_density, float* g_rgb, float* g_aux,
+                                      float* g_background, void* scratch, int64_t scratch_bytes, lnrf_stream_t stream) {
+  if (n_rays > 0 && g_background)
+    LNRF_CHECK_ARG(scratch && scratch_bytes >= lnrf_composite_bwd_scratch_bytes(n_rays) &&
+                       (reinterpret_cast<uintptr_t>(scratch) & 15u) == 0, "scratch too small or unaligned");
+  return composite_bwd_impl(ts, t_min, t_max, mask, density, rgb, aux, n_aux, background, n_rays, t, g_out, outputs,
+                            targets, target_stride, out_scale, g_aux_w, g_density, g_rgb, g_aux, g_background,
+                            reinterpret_cast<float*>(scratch), stream);
 }
 
 extern "C" int lnrf_fine_sample(const float* ts_c, const float* t_min, const float* t_max,

@@ -55,11 +55,18 @@ PROTOTYPES = {
                                      _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "lnrf_composite_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, _P, _P,
                                      c_int64, c_float, _F3, _P, _P, _P, _P, _P]),
+    "lnrf_composite_bwd_scratch_bytes": (c_int64, [c_int64]),
+    "lnrf_composite_bwd_det": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, _P, _P,
+                                         c_int64, c_float, _F3, _P, _P, _P, _P, _P, c_int64, _P]),
     "lnrf_sinusoidal_emb": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P]),
     "lnrf_dense_fwd": (c_int32, [_P, c_int64, _P, _P, c_int32, _P, c_int64, c_int64, c_int32, c_int32, _P]),
     "lnrf_act_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int32, c_int64, c_int32, _P]),
     "lnrf_dense_bwd_input": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, c_int32, c_int32, _P]),
     "lnrf_dense_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P]),
+    "lnrf_gemm_f32_det_scratch_bytes": (c_int64, [c_int64, c_int32, c_int64]),
+    "lnrf_gemm_f32_det": (c_int32, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int32, c_int64, _P, c_int64, _P]),
+    "lnrf_dense_bwd_weight_scratch_bytes": (c_int64, [c_int64, c_int32, c_int32]),
+    "lnrf_dense_bwd_weight_det": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P]),
     "lnrf_gemm_f32": (c_int32, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P, c_int32, c_int32,
                                 c_int64, c_int32, c_int64, c_int32, _P]),
     "lnrf_hashgrid_fwd": (c_int32, [POINTER(HashGridDesc), _P, _P, c_int64, _P, _P]),

@@ -154,11 +154,15 @@ def composite_bwd(ts, t_min, t_max, mask, density, rgb, background, g_background
         tstride = targets.stride(0)
         tptr = L.c_void_p(targets.data_ptr())
     gw = (L.c_float * 4)(*([float(x) for x in g_aux_w] + [0.0] * (4 - len(g_aux_w))))
-    L.check(L.lib().lnrf_composite_bwd(
+    # fixed-order background gradient (bit-reproducible step): per-workgroup partial sums in a leased scratch block
+    nbytes = L.lib().lnrf_composite_bwd_scratch_bytes(n)
+    lease = _ws.lease("composite_bwd", nbytes, dev)
+    L.check(L.lib().lnrf_composite_bwd_det(
         L.ptr(ts), L.ptr(t_min), L.ptr(t_max), L.ptr(mask, torch.uint8), L.ptr(density), L.ptr(rgb),
         L.ptr(aux), n_aux, L.ptr(background), n, t, L.ptr(g_out), L.ptr(outputs), tptr, tstride,
-        float(out_scale), gw, L.ptr(g_density), L.ptr(g_rgb), L.ptr(g_aux), L.ptr(g_background), L.stream()),
-        "composite_bwd")
+        float(out_scale), gw, L.ptr(g_density), L.ptr(g_rgb), L.ptr(g_aux), L.ptr(g_background),
+        L.ptr(lease.buf, torch.uint8), nbytes, L.stream()), "composite_bwd_det")
+    lease.release()
     return g_density, g_rgb, g_aux
 
 
@@ -262,19 +266,34 @@ def dense_bwd_weight(x: torch.Tensor, gy: torch.Tensor, gw: torch.Tensor, gb: Op
     m, k = x.shape
     m2, n = gy.shape
     assert m == m2 and gw.shape == (k, n) and gw.is_contiguous()
-    L.check(L.lib().lnrf_dense_bwd_weight(_vptr(x), _ld(x), _vptr(gy), _ld(gy), L.ptr(gw), L.ptr(gb), m, k, n,
-                                          L.stream()), "dense_bwd_weight")
+    # fixed-order split reduction (bit-reproducible), partial sums in a leased scratch block
+    nbytes = L.lib().lnrf_dense_bwd_weight_scratch_bytes(m, k, n)
+    lease = _ws.lease("dense_wgrad", nbytes, _dev(x))
+    L.check(L.lib().lnrf_dense_bwd_weight_det(_vptr(x), _ld(x), _vptr(gy), _ld(gy), L.ptr(gw), L.ptr(gb), m, k, n,
+                                              L.ptr(lease.buf, torch.uint8), nbytes, L.stream()), "dense_bwd_weight_det")
+    lease.release()
 
 
 def bias_grad(gy: torch.Tensor, gb: torch.Tensor):
     m, n = gy.shape
-    L.check(L.lib().lnrf_dense_bwd_weight(None, 0, _vptr(gy), _ld(gy), None, L.ptr(gb), m, 0, n, L.stream()),
-            "bias_grad")
+    nbytes = L.lib().lnrf_dense_bwd_weight_scratch_bytes(m, 0, n)
+    lease = _ws.lease("dense_wgrad", nbytes, _dev(gy))
+    L.check(L.lib().lnrf_dense_bwd_weight_det(None, 0, _vptr(gy), _ld(gy), None, L.ptr(gb), m, 0, n,
+                                              L.ptr(lease.buf, torch.uint8), nbytes, L.stream()), "bias_grad")
+    lease.release()
 
 
 def gemm(a: torch.Tensor, sa_i: int, sa_r: int, b: torch.Tensor, sb_r: int, sb_j: int, c: torch.Tensor, ldc: int,
          i_rows: int, j_cols: int, r_depth: int, bias=None, act: int = 0, mode: int = 0, splits: int = 0):
-    """C[i*ldc+j] (op)= sum_r A[i*sa_i + r*sa_r] * B[r*sb_r + j*sb_j] (see lnrf_gemm_f32)."""
+    """C[i*ldc+j] (op)= sum_r A[i*sa_i + r*sa_r] * B[r*sb_r + j*sb_j] (see lnrf_gemm_f32).  mode 2 (split reduction) with
+    contiguous C rows takes the fixed-order form lnrf_gemm_f32_det (bit-reproducible) instead of fp32 atomics."""
+    if mode == 2 and ldc == j_cols and bias is None and splits == 0:
+        nbytes = L.lib().lnrf_gemm_f32_det_scratch_bytes(i_rows, j_cols, r_depth)
+        lease = _ws.lease("gemm_det", nbytes, _dev(a))
+        L.check(L.lib().lnrf_gemm_f32_det(_vptr(a), sa_i, sa_r, _vptr(b), sb_r, sb_j, _vptr(c), i_rows, j_cols, r_depth,
+                                          L.ptr(lease.buf, torch.uint8), nbytes, L.stream()), "gemm_f32_det")
+        lease.release()
+        return c
     L.check(L.lib().lnrf_gemm_f32(_vptr(a), sa_i, sa_r, _vptr(b), sb_r, sb_j, _vptr(c), ldc, L.ptr(bias), act, mode,
                                   i_rows, j_cols, r_depth, splits, L.stream()), "gemm_f32")
     return c

@@ -211,3 +211,34 @@ def test_losses_no_grad_and_checkpoint_roundtrip(tmp_path):
     assert torch.equal(loop2.flat, loop.flat)
     t2, _ = loop2.losses(7, BMIN, BMAX, batch)
     assert abs(float(t2) - float(total)) < 1e-6  # per-block partial sums are combined by fp32 atomics
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_train_steps_are_bit_reproducible(precision):
+    """Two runs of the same steps from the same seed end with bit-identical parameters and Adam moments, on the fused path
+    (layer-stationary backward: fixed-order fold of the per-pipeline partial sums) and on the exact-fp32 dense path
+    (lnrf_dense_bwd_weight_det, fixed-order background gradient in lnrf_composite_bwd_det): no sum of the step depends on
+    the arrival order of workgroups.  What makes a PSNR comparison between two arithmetics mean something (an fp32 run no
+    longer differs from itself)."""
+    from learn_nerf.model import NeRFModel
+    from learn_nerf.rng import Key
+    from learn_nerf.train import TrainLoop
+
+    n, tc, tf = 512, 16, 32
+    gen = torch.Generator().manual_seed(3)
+    o = torch.randn(n, 3, generator=gen)
+    o = 4 * o / o.norm(dim=-1, keepdim=True)
+    d = -o + (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+    d = d / d.norm(dim=-1, keepdim=True)
+    batch = torch.stack([o, d, torch.rand(n, 3, generator=gen) * 2 - 1], 1).float().contiguous().cuda()
+    ends = []
+    for _ in range(2):
+        loop = TrainLoop(NeRFModel(precision=precision), NeRFModel(precision=precision), init_rng=0, lr=1e-3,
+                         coarse_ts=tc, fine_ts=tf)
+        step = loop.step_fn((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
+        for i in range(4):
+            step(Key(i), batch)
+        torch.cuda.synchronize()
+        ends.append((loop.flat.clone(), loop.state.opt_m.clone(), loop.state.opt_v.clone()))
+    for a, b in zip(*ends):
+        assert torch.equal(a, b)
