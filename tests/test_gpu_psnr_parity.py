@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "learn-nerf_amd", "learn_nerf", "scripts")
 
 SIZE, FOV, RADIUS = 32, math.radians(40.0), 2.5
 BMIN, BMAX = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
-TC, TF, BATCH = 32, 64, 1024
+TC, TF, BATCH = 16, 32, 512
 
 
 def cube_views(count, seed):
@@ -64,11 +64,13 @@ def held_out_psnr(loop, views):
 # the SIGN of bf16 - fp32 flips between checkpoints), far more than the 0.1 dB to be resolved.  The comparison is
 # therefore made after annealing the step size (the reference has no schedule, train.py:59; TrainLoop.lr is a plain
 # attribute) and on the mean squared error accumulated over the last EVAL_POINTS checkpoints.
-SCHEDULE = ((1500, 5e-4), (1000, 1e-4), (800, 2e-5))
-EVAL_EVERY, EVAL_POINTS = 100, 8
+SCHEDULE = ((900, 5e-4), (500, 1e-4), (300, 2e-5))
+EVAL_EVERY, EVAL_POINTS = 50, 8
 
-
-SEEDS = (5, 6, 7, 8)
+# Independent initialisations / batch orders.  Both arithmetics are bit-reproducible (tests/test_gpu_train_step.py::
+# test_train_steps_are_bit_reproducible), so every per-seed difference is a fixed number for a given build; seeds are added
+# until the standard error of their mean is at most SE_TARGET (measured: sample std 0.08-0.11 dB, i.e. 8-14 seeds of ~13 s).
+MIN_SEEDS, MAX_SEEDS, SE_TARGET = 8, 24, 0.03
 
 
 def train(precision, train_rays, test_views, key_offset=0, init_seed=5):
@@ -99,35 +101,30 @@ def train(precision, train_rays, test_views, key_offset=0, init_seed=5):
 
 def test_bf16_training_matches_fp32_psnr():
     """
-    Training is chaotic: two fp32 runs that differ only in their stratified-sampling noise end 0.1-0.2 dB apart (the
-    "noise floor" line below), and so do runs whose weight-gradient sums are merely ordered differently.  A single
-    bf16 - fp32 difference therefore cannot resolve 0.1 dB.  The gate is statistical: the mean difference over
-    N_SEEDS independent initialisations / batch orders must be within 0.1 dB of zero up to two standard errors of that
-    mean (estimated from the per-seed differences), i.e. the data must be compatible with |true difference| <= 0.1 dB;
-    the standard error itself must stay small enough for that statement to mean something.
+    north_star: PSNR within 0.1 dB of the (fp32) reference.  Training is chaotic — two runs that differ in ANY rounding end
+    0.1-0.2 dB apart — so one bf16 - fp32 difference cannot resolve 0.1 dB; the mean over independent seeds can.  Seeds
+    are added until the standard error of the mean difference is <= 0.03 dB, then the gate is the plain one:
+    |mean difference| <= 0.1 dB.
     """
     train_rays = torch.cat(cube_views(24, seed=0), dim=0)
     test_views = cube_views(8, seed=1234)
-    deltas = []
-    for init_seed in SEEDS:
-        bf16, bf16_tail = train("bf16", train_rays, test_views, init_seed=init_seed)
-        fp32, fp32_tail = train("fp32", train_rays, test_views, init_seed=init_seed)
+    deltas, se = [], float("inf")
+    for k in range(MAX_SEEDS):
+        init_seed = 100 + k
+        bf16, _ = train("bf16", train_rays, test_views, init_seed=init_seed)
+        fp32, _ = train("fp32", train_rays, test_views, init_seed=init_seed)
         print(f"seed {init_seed}: held-out PSNR (mean over the last {EVAL_POINTS} checkpoints) bf16-trained {bf16:.3f} dB, "
               f"fp32-trained {fp32:.3f} dB, delta {bf16 - fp32:+.3f} dB")
-        print("  bf16 tail:", " ".join(f"{p:.3f}" for p in bf16_tail))
-        print("  fp32 tail:", " ".join(f"{p:.3f}" for p in fp32_tail))
-        assert fp32 > 26.0, "the scene must actually be learnt for the comparison to mean anything"
+        assert fp32 > 25.0, "the scene must actually be learnt for the comparison to mean anything"
         assert abs(bf16 - fp32) < 0.75, "a single run this far off is not noise"
         deltas.append(bf16 - fp32)
-        if init_seed == SEEDS[0] and os.environ.get("LNRF_PSNR_NOISE_FLOOR") == "1":
-            # noise floor of the comparison itself (optional, +30 s): the same fp32 arithmetic with other
-            # stratified-sampling noise; measured -0.03 ... -0.15 dB between runs
-            fp32_b, _ = train("fp32", train_rays, test_views, key_offset=100_000, init_seed=init_seed)
-            print(f"  fp32 with other sampling noise {fp32_b:.3f} dB (noise floor {fp32_b - fp32:+.3f} dB)")
-    n = len(deltas)
-    mean_delta = sum(deltas) / n
-    std = math.sqrt(sum((d - mean_delta) ** 2 for d in deltas) / (n - 1))
-    se = std / math.sqrt(n)
+        n = len(deltas)
+        if n >= MIN_SEEDS:
+            mean_delta = sum(deltas) / n
+            std = math.sqrt(sum((d - mean_delta) ** 2 for d in deltas) / (n - 1))
+            se = std / math.sqrt(n)
+            if se <= SE_TARGET:
+                break
     print(f"mean delta over {n} seeds: {mean_delta:+.3f} dB, sample std {std:.3f} dB, standard error {se:.3f} dB")
-    assert se <= 0.15, "the comparison lost its resolution"
-    assert abs(mean_delta) <= 0.1 + 2.0 * se  # north_star: PSNR within 0.1 dB, at the resolution the noise allows
+    assert se <= SE_TARGET, "the comparison lost its resolution"
+    assert abs(mean_delta) <= 0.1  # north_star: PSNR within 0.1 dB
