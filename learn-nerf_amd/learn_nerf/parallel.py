@@ -106,18 +106,44 @@ class AbiComm:
         return cls(box[0], d.get_rank(), d.get_world_size())
 
     @classmethod
-    def from_file(cls, path: str, rank: int, world: int, timeout_s: float = 120.0) -> "AbiComm":
+    def from_file(cls, path: str, rank: int, world: int, nonce: str = "", timeout_s: float = 120.0) -> "AbiComm":
+        """Bootstrap through a shared file.  `nonce` must be the same on every rank and different for every launch (e.g.
+        MASTER_PORT or the launcher's pid): the id file is `path.<nonce>`, so an id left behind by an earlier launch can
+        never be read; the file also carries the nonce and is removed by rank 0 once every rank has joined (the first
+        collective of the communicator is the proof)."""
+        path = f"{path}.{nonce}" if nonce else path
+        tag = (nonce or "-").encode()
         if rank == 0:
+            if os.path.exists(path):
+                os.unlink(path)  # a leftover of a crashed launch with the same nonce
             with open(path + ".tmp", "wb") as fh:
-                fh.write(cls.new_unique_id())
+                fh.write(len(tag).to_bytes(4, "little") + tag + cls.new_unique_id())
             os.replace(path + ".tmp", path)
         deadline = time.time() + timeout_s
-        while not os.path.exists(path):
-            if time.time() > deadline:
-                raise TimeoutError(f"rank 0 never wrote the RCCL unique id to {path}")
-            time.sleep(0.05)
-        with open(path, "rb") as fh:
-            return cls(fh.read(), rank, world)
+        uid = None
+        while uid is None:
+            try:
+                with open(path, "rb") as fh:
+                    blob = fh.read()
+                n = int.from_bytes(blob[:4], "little")
+                if blob[4:4 + n] == tag and len(blob) == 4 + n + 128:
+                    uid = blob[4 + n:]
+            except FileNotFoundError:
+                pass
+            if uid is None:
+                if time.time() > deadline:
+                    raise TimeoutError(f"rank 0 never wrote the RCCL unique id of this launch to {path}")
+                time.sleep(0.05)
+        comm = cls(uid, rank, world)
+        probe = torch.zeros(1, device="cuda")
+        comm.all_reduce_sum_(probe)  # returns on every rank only after all of them have initialised
+        torch.cuda.synchronize()
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
+        return comm
 
     def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
         L = self._L

@@ -125,3 +125,59 @@ def test_train_step_at_8192_rays_per_gpu():
     whole = r.render_rays(Key(5), rays)["fine"]["outputs"]
     half = r.render_rays(Key(5, ray_offset=4096), rays[4096:].contiguous())["fine"]["outputs"]
     assert torch.equal(whole[4096:], half)
+
+
+@pytest.mark.parametrize("backward", ["ls", "split"])
+def test_single_rank_rccl_group_step_equals_plain_step(backward):
+    """The data-parallel sequence over RCCL itself (backend "nccl", one rank on this GPU): the step with a process group —
+    all-reduce of the flat gradient on RCCL's stream, for the two-launch backward also the EARLY asynchronous reduce of
+    the coarse slice underneath the fine backward (train.py: parallel.begin_reduce_ / reduce_gradient_) — must leave
+    bit-identical parameters and Adam moments to the step without a group.  Covers the stream ordering of the async
+    collective against grad.zero_(), the backward kernels and Adam, which the gloo runs cannot."""
+    import torch.distributed as dist
+
+    from learn_nerf.model import NeRFModel
+    from learn_nerf.rng import Key
+    from learn_nerf.train import TrainLoop
+
+    batch = global_batch().cuda()
+
+    def run():
+        loop = TrainLoop(NeRFModel(backward_kernel=backward), NeRFModel(backward_kernel=backward), init_rng=SEED, lr=LR,
+                         coarse_ts=TC, fine_ts=TF)
+        step = loop.step_fn(BMIN, BMAX)
+        for i in range(3):
+            step(Key(i), batch)
+        torch.cuda.synchronize()
+        return loop.flat.clone(), loop.state.opt_m.clone(), loop.state.opt_v.clone()
+
+    plain = run()
+    assert not dist.is_initialized()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        grouped = run()
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(plain, grouped):
+        assert torch.equal(a, b)
+
+
+def test_abi_comm_file_bootstrap_ignores_a_stale_id(tmp_path):
+    """AbiComm.from_file: an id file left by an earlier launch (other nonce, or the same path without one) must not be
+    picked up, and the file of this launch is gone once the communicator works."""
+    from learn_nerf.parallel import AbiComm
+
+    base = str(tmp_path / "uid")
+    with open(base + ".old", "wb") as fh:
+        fh.write(b"\\x03\\x00\\x00\\x00old" + b"\\x00" * 128)
+    with open(base + ".new", "wb") as fh:  # same name as this launch's file, but written by "an earlier crash"
+        fh.write(b"\\x03\\x00\\x00\\x00xyz" + b"\\x00" * 128)
+    comm = AbiComm.from_file(base, 0, 1, nonce="new")
+    v = torch.arange(8, dtype=torch.float32, device="cuda")
+    comm.all_reduce_sum_(v)
+    torch.cuda.synchronize()
+    assert torch.equal(v.cpu(), torch.arange(8, dtype=torch.float32))
+    comm.destroy()
+    assert not os.path.exists(base + ".new") and os.path.exists(base + ".old")
