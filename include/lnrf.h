@@ -476,6 +476,15 @@ int lnrf_ngp_mlp_pack(const lnrf_ngp_mlp_desc* desc, const float* params, void* 
 /* enc_t: [enc_dim][m] feature-major output of lnrf_hashgrid_fwd; d: [m][3]; density [m], rgb [m][3]. */
 int lnrf_ngp_mlp_fwd(const lnrf_ngp_mlp_desc* desc, const void* packed, const float* enc_t, const float* d,
                      int64_t m, float* density, float* rgb, lnrf_stream_t stream);
+/* The same forward in split precision ("bf16x3", the render / evaluation path): every fp32 operand is carried as a
+ * bf16 pair hi + lo and every product is lo*hi + hi*lo + hi*hi on the bf16 MFMA with fp32 accumulation, which
+ * reproduces the reference's fp32 arithmetic (instant_ngp.py:38-54) to ~1e-5, so that rendered RGB meets the 1e-3
+ * gate.  packed_split: lnrf_ngp_mlp_packed_split_bytes bytes, written by lnrf_ngp_mlp_pack_split. */
+int64_t lnrf_ngp_mlp_packed_split_bytes(const lnrf_ngp_mlp_desc* desc);
+int lnrf_ngp_mlp_pack_split(const lnrf_ngp_mlp_desc* desc, const float* params, void* packed_split,
+                            lnrf_stream_t stream);
+int lnrf_ngp_mlp_fwd_split(const lnrf_ngp_mlp_desc* desc, const void* packed_split, const float* enc_t,
+                           const float* d, int64_t m, float* density, float* rgb, lnrf_stream_t stream);
 /* VJP of lnrf_ngp_mlp_fwd (recomputes the forward): g_enc_t [enc_dim][m] = d loss / d enc (written),
  * grads (the flat gradient vector, same layout as params) += Dense kernel / bias gradients.
  * level_absmax (optional): enc_dim / 2 floats ZEROED by the caller; on return level_absmax[l] = max |g_enc_t| over

@@ -613,6 +613,215 @@ struct NgpOffsets {
   int64_t w[kNgpLayers], b[kNgpLayers];
 };
 
+// parameter feeding element (lane, j) of forward A-fragment g (stream order = consumption order); -1 = zero padding
+__device__ __forceinline__ int64_t ngp_fwd_param_index(int g, int lane, int j, const NgpOffsets& off, int lf, int ne) {
+  const int r = lane & 31, hh = lane >> 5;
+  const int fo = 8 * (j >> 2) + 4 * hh + (j & 3);  // feature offset of k slot (hh, j) within its k-step
+  int l = 0;
+  for (int i = 1; i < kNgpLayers; ++i)
+    if (g >= ngp_fwd_base(i, ne)) l = i;
+  const int loc = g - ngp_fwd_base(l, ne), nk = ngp_fwd_nk(l, ne);
+  const int o = loc / nk, ks = loc % nk;
+  const int row = 32 * o + r, od = ngp_out_dim(l);
+  int k = -1;
+  if (l == 0) k = (16 * ks + fo < lf) ? 16 * ks + fo : -1;
+  else if (l == 2) k = ks == 0 ? fo : (ks == 1 ? (fo < 8 ? 16 + fo : -1) : kNgpDembDim + fo);
+  else k = 16 * ks + fo;
+  return (row < od && k >= 0) ? off.w[l] + (int64_t)k * od + row : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-precision forward ("bf16x3", the render / evaluation path; instant_ngp.py:38-54 is fp32 in the reference): every
+// fp32 operand — weight, hash-grid feature, direction embedding, activation — is a bf16 pair (hi, lo) with hi + lo equal
+// to the value to 16 significant bits and every product is lo*hi + hi*lo + hi*hi on the bf16 MFMA with fp32 accumulation,
+// as nerf_fwd_split_kernel does for NeRFModel.  The whole stream ([hi, lo] per forward fragment: at most 52 KiB) is
+// staged in LDS once per persistent workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNgpSplitMaxFrags = 2 * 26;
+constexpr int kNgpSplitBiasOff = kNgpSplitMaxFrags * kFragBytes;
+constexpr int kNgpSplitBytes = kNgpSplitBiasOff + kNgpBiasFloats * 4;
+
+__global__ void ngp_pack_split_kernel(const float* __restrict__ params, NgpOffsets off, int lf, int ne,
+                                      char* __restrict__ packed) {
+  const int total_w = kNgpSplitMaxFrags * 512;
+  const int total = total_w + kNgpBiasFloats;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    if (e < total_w) {
+      const int gg = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+      const int g = gg >> 1;
+      const int64_t idx = g < ngp_fwd_count(ne) ? ngp_fwd_param_index(g, lane, j, off, lf, ne) : -1;
+      const float w = idx >= 0 ? params[idx] : 0.0f;
+      const __bf16 hi = (__bf16)w;
+      reinterpret_cast<__bf16*>(packed)[e] = (gg & 1) ? (__bf16)(w - (float)hi) : hi;
+    } else {
+      const int i = e - total_w;
+      int l = 0;
+      for (int k = 1; k < kNgpLayers; ++k)
+        if (i >= ngp_bias_base(k)) l = k;
+      const int loc = i - ngp_bias_base(l);
+      reinterpret_cast<float*>(packed + kNgpSplitBiasOff)[i] = loc < ngp_out_dim(l) ? params[off.b[l] + loc] : 0.0f;
+    }
+  }
+}
+
+__device__ __forceinline__ void ngp_split(float v, bf16x8& hi, bf16x8& lo, int j) {
+  const __bf16 hb = (__bf16)v;
+  hi[j] = hb;
+  lo[j] = (__bf16)(v - (float)hb);
+}
+template <int S, bool RELU>
+__device__ __forceinline__ void ngp_acc_split(const f32x16& acc, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc[8 * S + j];
+    if (RELU) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
+    ngp_split(v, hi, lo, j);
+  }
+}
+
+template <int NE>
+__global__ __launch_bounds__(kThreads) void ngp_mlp_fwd_split_kernel(
+    const char* __restrict__ packed3, const float* __restrict__ enc_t, const float* __restrict__ d_g, int lf, int64_t M,
+    int64_t n_tiles, float* __restrict__ density, float* __restrict__ rgb) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  for (int i = tid; i < kNgpSplitBytes / 16; i += kThreads)
+    reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(packed3)[i];
+  __syncthreads();
+  const float* bias_l = reinterpret_cast<const float*>(smem + kNgpSplitBiasOff);
+  // the per-lane LDS offset is made opaque once per group: the stream does not change, so the compiler would otherwise
+  // hoist all 52 fragment reads (208 registers) out of the group loop and spill them
+  int lds_lane = lane * 16;
+  auto afrag = [&](int g, int part) -> bf16x8 {
+    return bits_to_frag(*reinterpret_cast<const uint4*>(smem + (2 * g + part) * kFragBytes + lds_lane));
+  };
+  auto bias_tile = [&](int row0) -> f32x16 {  // accumulator rows (q & 3) + 8 (q >> 2) + 4 h of the 32-row tile at row0
+    f32x16 acc;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 v = *reinterpret_cast<const float4*>(bias_l + row0 + 4 * h + 8 * gq);
+      acc[4 * gq + 0] = v.x; acc[4 * gq + 1] = v.y; acc[4 * gq + 2] = v.z; acc[4 * gq + 3] = v.w;
+    }
+    return acc;
+  };
+  // one layer: out tiles x k-steps, three MFMAs per product (small terms first)
+  auto layer = [&](auto g0_, auto nk_, auto no_, int bias0, auto&& bhi, auto&& blo, auto&& epi) {
+    constexpr int G0 = decltype(g0_)::value, NK = decltype(nk_)::value, NO = decltype(no_)::value;
+    static_for<NO>([&](auto o_) {
+      constexpr int o = decltype(o_)::value;
+      f32x16 acc = bias_tile(bias0 + 32 * o);
+      static_for<NK>([&](auto k_) {
+        constexpr int ks = decltype(k_)::value;
+        const bf16x8 ahi = afrag(G0 + o * NK + ks, 0), alo = afrag(G0 + o * NK + ks, 1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi(k_), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo(k_), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi(k_), acc, 0, 0, 0);
+      });
+      epi(o_, acc);
+    });
+  };
+  const int64_t n_groups = n_tiles / kWaves;
+  for (int64_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+    asm volatile("" : "+v"(lds_lane));
+    const int64_t tile = group * kWaves + wave;
+    const int64_t m = tile * kTileCols + c;
+    const bool valid = m < M;
+    const int64_t mm = valid ? m : M - 1;
+    bf16x8 ef_hi[NE], ef_lo[NE];
+    static_for<NE>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int feat = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        const float v = (valid && feat < lf) ? enc_t[(int64_t)(feat < lf ? feat : lf - 1) * M + mm] : 0.0f;
+        ngp_split(v, ef_hi[ks], ef_lo[ks], j);
+      }
+    });
+    float pd[3] = {0, 0, 0};
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) pd[a] = d_g[m * 3 + a];
+    }
+    bf16x8 de_hi[2], de_lo[2];  // sinusoidal direction embedding (model.py:65-77): feature e = 8 coord + 4 is_cos + freq
+    static_for<2>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float v = 0.0f;
+        if (e < kNgpDembDim) {
+          const int cd = e >> 3, fr = e & 3;
+          const float x = cd == 0 ? pd[0] : (cd == 1 ? pd[1] : pd[2]);
+          float sn, co;
+          sincos_pe(x * (float)(1 << fr), &sn, &co);
+          v = (e & 4) ? co : sn;
+        }
+        ngp_split(v, de_hi[ks], de_lo[ks], j);
+      }
+    });
+    bf16x8 h0h[4], h0l[4], o16h, o16l, c1h[4], c1l[4], c2h[4], c2l[4];
+    float logit = 0.0f, y[3] = {0, 0, 0};
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    layer(std::integral_constant<int, ngp_fwd_base(0, NE)>{}, std::integral_constant<int, NE>{}, std::integral_constant<int, 2>{},
+          ngp_bias_base(0), [&](auto k_) -> bf16x8 { return ef_hi[decltype(k_)::value]; },
+          [&](auto k_) -> bf16x8 { return ef_lo[decltype(k_)::value]; },
+          [&](auto o_, const f32x16& acc) {
+            constexpr int o = decltype(o_)::value;
+            ngp_acc_split<0, true>(acc, h0h[2 * o], h0l[2 * o]);
+            ngp_acc_split<1, true>(acc, h0h[2 * o + 1], h0l[2 * o + 1]);
+          });
+    layer(std::integral_constant<int, ngp_fwd_base(1, NE)>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{},
+          ngp_bias_base(1), [&](auto k_) -> bf16x8 { return h0h[decltype(k_)::value]; },
+          [&](auto k_) -> bf16x8 { return h0l[decltype(k_)::value]; },
+          [&](auto, const f32x16& acc) {
+            ngp_acc_split<0, false>(acc, o16h, o16l);
+            logit = acc[0];
+          });
+    layer(std::integral_constant<int, ngp_fwd_base(2, NE)>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{},
+          ngp_bias_base(2),
+          [&](auto k_) -> bf16x8 {
+            constexpr int ks = decltype(k_)::value;
+            if constexpr (ks < 2) return de_hi[ks];
+            else return o16h;
+          },
+          [&](auto k_) -> bf16x8 {
+            constexpr int ks = decltype(k_)::value;
+            if constexpr (ks < 2) return de_lo[ks];
+            else return o16l;
+          },
+          [&](auto o_, const f32x16& acc) {
+            constexpr int o = decltype(o_)::value;
+            ngp_acc_split<0, true>(acc, c1h[2 * o], c1l[2 * o]);
+            ngp_acc_split<1, true>(acc, c1h[2 * o + 1], c1l[2 * o + 1]);
+          });
+    layer(std::integral_constant<int, ngp_fwd_base(3, NE)>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{},
+          ngp_bias_base(3), [&](auto k_) -> bf16x8 { return c1h[decltype(k_)::value]; },
+          [&](auto k_) -> bf16x8 { return c1l[decltype(k_)::value]; },
+          [&](auto o_, const f32x16& acc) {
+            constexpr int o = decltype(o_)::value;
+            ngp_acc_split<0, true>(acc, c2h[2 * o], c2l[2 * o]);
+            ngp_acc_split<1, true>(acc, c2h[2 * o + 1], c2l[2 * o + 1]);
+          });
+    layer(std::integral_constant<int, ngp_fwd_base(4, NE)>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{},
+          ngp_bias_base(4), [&](auto k_) -> bf16x8 { return c2h[decltype(k_)::value]; },
+          [&](auto k_) -> bf16x8 { return c2l[decltype(k_)::value]; },
+          [&](auto, const f32x16& acc) {
+            y[0] = tanhf(acc[0]);
+            y[1] = tanhf(acc[1]);
+            y[2] = tanhf(acc[2]);
+          });
+    if (h == 0 && valid) {
+      density[m] = expf(logit);  // instant_ngp.py:49
+      rgb[m * 3 + 0] = y[0];
+      rgb[m * 3 + 1] = y[1];
+      rgb[m * 3 + 2] = y[2];
+    }
+  }
+}
+
 __global__ void ngp_pack_kernel(const float* __restrict__ params, NgpOffsets off, int lf, int ne,
                                 char* __restrict__ packed) {
   const int total_frag_elems = kNgpStreamFrags * 512;
@@ -625,17 +834,7 @@ __global__ void ngp_pack_kernel(const float* __restrict__ params, NgpOffsets off
       int64_t idx = -1;
       const int nfwd = ngp_fwd_count(ne);
       if (g < nfwd) {
-        int l = 0;
-        for (int i = 1; i < kNgpLayers; ++i)
-          if (g >= ngp_fwd_base(i, ne)) l = i;
-        const int loc = g - ngp_fwd_base(l, ne), nk = ngp_fwd_nk(l, ne);
-        const int o = loc / nk, ks = loc % nk;
-        const int row = 32 * o + r, od = ngp_out_dim(l);
-        int k = -1;
-        if (l == 0) k = (16 * ks + fo < lf) ? 16 * ks + fo : -1;
-        else if (l == 2) k = ks == 0 ? fo : (ks == 1 ? (fo < 8 ? 16 + fo : -1) : kNgpDembDim + fo);
-        else k = 16 * ks + fo;
-        if (row < od && k >= 0) idx = off.w[l] + (int64_t)k * od + row;
+        idx = ngp_fwd_param_index(g, lane, j, off, lf, ne);
       } else if (g < ngp_total_count(ne)) {
         int t = 0;
         for (int i = 1; i < kNgpLayers; ++i)
@@ -742,6 +941,52 @@ extern "C" int lnrf_ngp_mlp_pack(const lnrf_ngp_mlp_desc* desc, const float* par
   const int ne = desc->enc_dim <= 16 ? 1 : 2;
   hipLaunchKernelGGL(ngp_pack_kernel, dim3(64), dim3(256), 0, as_stream(stream), params, ngp_offsets(desc),
                      (int)desc->enc_dim, ne, (char*)packed);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int64_t lnrf_ngp_mlp_packed_split_bytes(const lnrf_ngp_mlp_desc* desc) {
+  return ngp_supported(desc) ? kNgpSplitBytes : -1;
+}
+
+extern "C" int lnrf_ngp_mlp_pack_split(const lnrf_ngp_mlp_desc* desc, const float* params, void* packed_split,
+                                       lnrf_stream_t stream) {
+  NGP_REQUIRE_SUPPORTED("lnrf_ngp_mlp_pack_split");
+  LNRF_CHECK_ARG(params && packed_split, "null pointer");
+  LNRF_CHECK_ARG(desc->dense_offset >= 0, "bad dense_offset");
+  const int ne = desc->enc_dim <= 16 ? 1 : 2;
+  hipLaunchKernelGGL(ngp_pack_split_kernel, dim3(64), dim3(256), 0, as_stream(stream), params, ngp_offsets(desc),
+                     (int)desc->enc_dim, ne, (char*)packed_split);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_ngp_mlp_fwd_split(const lnrf_ngp_mlp_desc* desc, const void* packed_split, const float* enc_t,
+                                      const float* d, int64_t m, float* density, float* rgb, lnrf_stream_t stream) {
+  NGP_REQUIRE_SUPPORTED("lnrf_ngp_mlp_fwd_split");
+  LNRF_CHECK_ARG(m >= 0, "bad m");
+  if (m == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(packed_split && enc_t && d && density && rgb, "null pointer");
+  const int64_t n_tiles = ngp_tiles(m);
+  int dev = 0, cus = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute(multiprocessor count)");
+  int64_t nb = n_tiles / kWaves;
+  if (nb > 2 * (int64_t)cus) nb = 2 * (int64_t)cus;  // persistent: the stream is staged in LDS once per workgroup
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (desc->enc_dim <= 16) {
+    rc = ngp_ensure_lds(ngp_mlp_fwd_split_kernel<1>, kNgpSplitBytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_fwd_split_kernel<1>), dim3((unsigned)nb), dim3(kThreads), kNgpSplitBytes, st,
+                       (const char*)packed_split, enc_t, d, (int)desc->enc_dim, m, n_tiles, density, rgb);
+  } else {
+    rc = ngp_ensure_lds(ngp_mlp_fwd_split_kernel<2>, kNgpSplitBytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL((ngp_mlp_fwd_split_kernel<2>), dim3((unsigned)nb), dim3(kThreads), kNgpSplitBytes, st,
+                       (const char*)packed_split, enc_t, d, (int)desc->enc_dim, m, n_tiles, density, rgb);
+  }
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }

@@ -117,6 +117,9 @@ PROTOTYPES = {
     "lnrf_ngp_mlp_scratch_bytes": (c_int64, [POINTER(NgpMlpDesc), c_int64]),
     "lnrf_ngp_mlp_pack": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P]),
     "lnrf_ngp_mlp_fwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_ngp_mlp_packed_split_bytes": (c_int64, [POINTER(NgpMlpDesc)]),
+    "lnrf_ngp_mlp_pack_split": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P]),
+    "lnrf_ngp_mlp_fwd_split": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, c_int64, _P, _P, _P]),
     "lnrf_ngp_mlp_bwd": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "lnrf_dense_bwd_input_gated": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, c_int32,
                                              c_int64, c_int32, c_int32, _P]),

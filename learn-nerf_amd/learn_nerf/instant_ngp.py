@@ -111,6 +111,9 @@ class InstantNGPModel(ModelBase):
     density_layers: int = 1
     color_layers: int = 2
     precision: str = "bf16"  # "bf16" (fused MFMA MLP, lnrf_ngp_mlp_*) | "fp32" (exact dense path)
+    # fused path, forward without a backward (rendering, evaluation, model.apply): "bf16x3" = split-precision kernel
+    # (lnrf_ngp_mlp_fwd_split: the reference's fp32 arithmetic to ~1e-5) | "bf16" = the training forward's plain operands
+    render_precision: str = "bf16x3"
     tag: str = "ngp"
 
     _pack_cache: Any = field(default=None, repr=False, compare=False)
@@ -139,24 +142,31 @@ class InstantNGPModel(ModelBase):
                             self.density_layers, self.color_layers, self.d_freqs,
                             self.encoding().num_table_floats())
 
-    def packed_weights(self, flat: torch.Tensor) -> torch.Tensor:
-        """bf16 MFMA-fragment copy of the Dense parameters; rebuilt when the flat buffer changes.  As in
+    def packed_weights(self, flat: torch.Tensor, kind: str = "bf16") -> torch.Tensor:
+        """bf16 MFMA-fragment copy of the Dense parameters ("bf16": forward + transposed streams; "split": hi/lo pairs
+        of the forward stream for the render kernel); rebuilt when the flat buffer changes.  As in
         NeRFModel.packed_weights: a miss packs into a fresh buffer (a saved backward context may hold the old
         one) and cache entries keep their source tensor alive so that a recycled address cannot hit."""
         if self._pack_cache is None:
             self._pack_cache = OrderedDict()
-        key = (flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
+        key = (kind, flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
         hit = self._pack_cache.get(key)
         if hit is not None:
             self._pack_cache.move_to_end(key)
             return hit[1]
         desc = self._mlp_desc()
-        nbytes = L.lib().lnrf_ngp_mlp_packed_bytes(ctypes.byref(desc))
-        packed = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
-        L.check(L.lib().lnrf_ngp_mlp_pack(ctypes.byref(desc), L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
-                "ngp_mlp_pack")
+        if kind == "split":
+            nbytes = L.lib().lnrf_ngp_mlp_packed_split_bytes(ctypes.byref(desc))
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+            L.check(L.lib().lnrf_ngp_mlp_pack_split(ctypes.byref(desc), L.ptr(flat), L.ptr(packed, torch.uint8),
+                                                    L.stream()), "ngp_mlp_pack_split")
+        else:
+            nbytes = L.lib().lnrf_ngp_mlp_packed_bytes(ctypes.byref(desc))
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+            L.check(L.lib().lnrf_ngp_mlp_pack(ctypes.byref(desc), L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
+                    "ngp_mlp_pack")
         self._pack_cache[key] = (flat, packed)
-        while len(self._pack_cache) > 4:
+        while len(self._pack_cache) > 6:
             self._pack_cache.popitem(last=False)
         return packed
 
@@ -165,12 +175,21 @@ class InstantNGPModel(ModelBase):
         tables, _ = self._dense_views(flat)
         m, dev = x.shape[0], flat.device
         desc = self._mlp_desc()
-        packed = self.packed_weights(flat)
+        if self.render_precision not in ("bf16x3", "bf16"):
+            raise ValueError(f"unknown render_precision {self.render_precision!r}")
         with _prof.section(f"{self.tag}_hashgrid_fwd"):
             enc_t = enc.encode_t(tables, x)  # [L*F, M]
         density = torch.empty(m, dtype=F32, device=dev)
         rgb = torch.empty((m, 3), dtype=F32, device=dev)
         d = d.contiguous()
+        if not save and self.render_precision == "bf16x3":
+            packed3 = self.packed_weights(flat, "split")
+            with _prof.section(f"{self.tag}_mlp_fwd_split"):
+                L.check(L.lib().lnrf_ngp_mlp_fwd_split(ctypes.byref(desc), L.ptr(packed3, torch.uint8), L.ptr(enc_t),
+                                                       L.ptr(d), m, L.ptr(density), L.ptr(rgb), L.stream()),
+                        "ngp_mlp_fwd_split")
+            return density, rgb, {}, None
+        packed = self.packed_weights(flat)
         with _prof.section(f"{self.tag}_mlp_fwd"):
             L.check(L.lib().lnrf_ngp_mlp_fwd(ctypes.byref(desc), L.ptr(packed, torch.uint8), L.ptr(enc_t), L.ptr(d),
                                              m, L.ptr(density), L.ptr(rgb), L.stream()), "ngp_mlp_fwd")

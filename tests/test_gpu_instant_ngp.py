@@ -121,7 +121,9 @@ def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m, monkeypatch):
     assert model._use_fused()
     x, d, gen = points(m, seed=levels)
     _, _, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+    model.render_precision = "bf16"  # the plain-operand kernel (= the training forward) is what this test compares
     dens, rgb, _, _ = model.forward_points(flat, x.cuda(), d.cuda(), save=False)
+    model.render_precision = "bf16x3"
     assert ctx["kind"] == "fused"
     f32 = flat.cpu().float().requires_grad_(True)
     rd, rr, _ = ON.ngp_model(f32, x, d, model.table_sizes, model.grid_sizes, BMIN, BMAX, operand_round=bf16_round)
@@ -155,6 +157,79 @@ def test_ngp_fused_mlp_vs_bf16_oracle(levels, table, m, monkeypatch):
     # a second backward into the same buffer accumulates
     model.backward(ctx, g_d.cuda(), g_c.cuda(), None, grad)
     assert ((grad.cpu() - 2 * got).norm() / got.norm()).item() < 1e-3
+
+
+@pytest.mark.parametrize("levels,table,m", [(6, 2 ** 12, 2500), (16, 2 ** 14, 4133), (3, 2 ** 10, 31), (16, 2 ** 14, 70000)])
+def test_ngp_fused_split_forward_matches_exact(levels, table, m):
+    """lnrf_ngp_mlp_fwd_split — the default for every forward without a backward (rendering, evaluation, model.apply): bf16
+    hi + lo operand pairs, three MFMAs per product, fp32 accumulate — against the EXACT float64 model
+    (instant_ngp.py:38-54 restated in oracle/instant_ngp.py): 5e-5 absolute on rgb, 5e-5 relative on density."""
+    model, params, flat = make_model(levels, table, precision="bf16")
+    assert model._use_fused() and model.render_precision == "bf16x3"
+    x, d, _ = points(m, seed=levels + 1)
+    dens, rgb, aux = model.apply(dict(params=params), x.cuda(), d.cuda())
+    ed, er, _ = ON.ngp_model(flat.cpu().double(), x.double(), d.double(), model.table_sizes, model.grid_sizes, BMIN, BMAX)
+    e_rgb = (rgb.cpu().double() - er).abs().max().item()
+    e_den = ((dens.cpu().double() - ed).abs() / (1e-3 + ed.abs())).max().item()
+    print(f"L={levels} m={m}: split-precision forward vs exact: rgb {e_rgb:.2e}, density rel {e_den:.2e}")
+    assert aux == {} and dens.shape == (m, 1) and rgb.shape == (m, 3)
+    assert e_rgb < 5e-5 and e_den < 5e-5
+
+
+def test_ngp_renderer_meets_the_1e3_gate_on_the_fused_path():
+    """north_star: rendered RGB within 1e-3 of the reference's fp32 arithmetic on identical rays.  NeRFRenderer over two
+    InstantNGPModels in their DEFAULT configuration (precision "bf16": fused kernels; the renderer's forwards carry no
+    backward, so the MLP runs lnrf_ngp_mlp_fwd_split) at 256 rays x (64 + 128) samples against the exact float64 oracle."""
+    from learn_nerf.instant_ngp import InstantNGPModel
+    from learn_nerf.render import NeRFRenderer
+    from learn_nerf.rng import Key, split
+    from learn_nerf.train import TrainLoop
+    from oracle import render as OR
+
+    def mk(levels):
+        return InstantNGPModel(table_sizes=[2 ** 14] * levels, grid_sizes=[2 ** (4 + i // 2) for i in range(levels)],
+                               bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3)
+
+    n, tc, tf = 256, 64, 128
+    loop = TrainLoop(mk(6), mk(16), init_rng=4, lr=1e-2, coarse_ts=tc, fine_ts=tf)
+    gen = torch.Generator().manual_seed(0)
+    for mdl, sl in ((loop.coarse, loop._slices(loop.flat)[0]), (loop.fine, loop._slices(loop.flat)[1])):
+        nt = mdl.encoding().num_table_floats()
+        sl[:nt] = ((torch.rand(nt, generator=gen) * 2 - 1) * 0.5).cuda()
+        # density = exp(logit): lift the logit so that some rays are opaque and compositing matters
+        off = nt
+        dims = mdl.dense_dims()
+        off += dims[0][0] * dims[0][1] + dims[0][1] + dims[1][0] * dims[1][1]
+        sl[off] += 2.0  # Dense_1 bias[0]
+    loop._params_changed()
+    o = torch.randn(n, 3, generator=gen)
+    o = 4 * o / o.norm(dim=-1, keepdim=True)
+    dd = -o + (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+    dd = dd / dd.norm(dim=-1, keepdim=True)
+    rays = torch.stack([o, dd], 1).float().contiguous()
+    p = loop.state.params
+    renderer = NeRFRenderer(coarse=loop.coarse, fine=loop.fine, coarse_params=p["coarse"], fine_params=p["fine"],
+                            background=p["background"], bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3, coarse_ts=tc,
+                            fine_ts=tf)
+    key = Key(321)
+    out = renderer.render_rays(key, rays.cuda())
+    ck, fk = split(key, 2)
+    uc = torch.from_numpy(philox.ray_uniforms(ck.seed, 0, 0, n, tc)).double()
+    uf = torch.from_numpy(philox.ray_uniforms(fk.seed, 1, 0, n, tf)).double()
+    cf, ff, bg = [t.cpu().double() for t in loop._slices(loop.flat)]
+
+    def make_fn(model, fl):
+        return lambda x, d: ON.ngp_model(fl, x, d, model.table_sizes, model.grid_sizes, (-1.0,) * 3, (1.0,) * 3)
+
+    ref = OR.render_hierarchy(make_fn(loop.coarse, cf), make_fn(loop.fine, ff), bg, torch.tensor([-1.0] * 3, dtype=F64),
+                              torch.tensor([1.0] * 3, dtype=F64), rays.double(), tc, tf, uc, uf)
+    for lvl in ("coarse", "fine"):
+        err = (out[lvl]["outputs"].cpu().double() - ref[lvl]["outputs"]).abs().max().item()
+        aerr = (out[lvl]["alphas"].cpu().double() - ref[lvl]["alphas"]).abs().max().item()
+        print(f"ngp renderer {lvl}: rgb max|d| vs exact oracle {err:.2e}, alpha {aerr:.2e}")
+        assert err < 1e-3 and aerr < 1e-3
+    alpha = ref["fine"]["alphas"]
+    assert alpha.max() > 0.5, "the test scene must have opaque rays"
 
 
 @pytest.mark.parametrize("levels,m", [(6, 2500), (16, 4133), (3, 31)])
