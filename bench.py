@@ -16,11 +16,12 @@ Rays shard data-parallel: every rank draws its own 4096 rays (weak scaling), gra
 all-reduced (sum) over RCCL and averaged inside the fused Adam kernel.
 
 Rank 0 prints ONE JSON line (see the task contract) with these extra objects:
-  roofline     — SURVEY.md 8(d): configs[1] is MFMA-bound, so the dominant kernel family's algorithmic FLOP per
-                 launch / its mean HIP-event time in the timed region (the weight-gradient family = nerf_wgrad_kernel +
-                 its ~0.03 ms slab-reduce launch) vs the dense bf16 MFMA peak of MI355X
-                 (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from the
-                 rocprofv3 PMC summary named in `traffic_source` (a separate profiling run, not this one)
+  roofline     — SURVEY.md 8(d): configs[1] is MFMA-bound, so the dominant kernel's algorithmic FLOP per launch / its
+                 mean HIP-event time in the timed region vs the dense bf16 MFMA peak of MI355X (2.5 PFLOP/s,
+                 /opt/skills/guides/MI355X_MICROARCH.md).  The dominant launch is nerf_bwd_ls_kernel, the persistent
+                 layer-stationary pipeline of BOTH models' backward (section bwd_ls_pipeline: Dense_8 .. Dense_1, input
+                 and weight gradients = 2,097,152 algorithmic FLOP per model evaluation); `traffic` = HBM bytes per
+                 launch from the rocprofv3 PMC summary named in `traffic_source` (a separate profiling run, not this one)
   roofline_hbm — the same kernel against the HBM roof (its design bytes per launch / time / 8 TB/s)
   cpu_baseline — the oracle's torch-CPU fp32 restatement of the same step on a bounded sample
                  (rank 0, N = 1 only); a reported baseline, not the optimisation target.
@@ -48,6 +49,12 @@ FLOP_FWD_PER_EVAL = 2 * 591_488
 FLOP_TRAIN_PER_RAY_SAMPLE = 4_641_792
 MAC_DGRAD_PER_EVAL = 557_696
 MAC_WGRAD_PER_EVAL = 591_488
+# layer-stationary backward: the persistent pipeline launch holds Dense_8 .. Dense_1 (input gradient + weight gradient of
+# the 256 x 256 kernels), the head launches Dense_11 / 10 / 9 -> dz, the finish launches the five small weight-gradient
+# problems (z x dy10m, x_emb x dy0, x_emb x dy5, d_emb x dy10m, h10 x dy11)
+MAC_LS_PIPELINE_PER_EVAL = 2 * 8 * 65_536
+MAC_LS_HEAD_PER_EVAL = 128 * 3 + 256 * 128 + 256
+MAC_LS_FINISH_PER_EVAL = MAC_DGRAD_PER_EVAL + MAC_WGRAD_PER_EVAL - MAC_LS_PIPELINE_PER_EVAL - MAC_LS_HEAD_PER_EVAL
 
 
 def synthetic_batch(n, seed, device):
@@ -373,8 +380,11 @@ def main():
         for name, (cnt, ms) in prof.items():
             lvl = "coarse" if name.startswith("coarse") else ("fine" if name.startswith("fine") else None)
             flops = None
-            if name == "bwd_ls":  # both models' backward in one family of launches (head, pipeline, small problems, folds)
-                flops = (m_c + m_f) * 2 * (MAC_DGRAD_PER_EVAL + MAC_WGRAD_PER_EVAL)
+            # layer-stationary backward of BOTH models: head launches, ONE persistent pipeline launch, finish launches
+            ls_mac = {"bwd_ls": MAC_DGRAD_PER_EVAL + MAC_WGRAD_PER_EVAL, "bwd_ls_head": MAC_LS_HEAD_PER_EVAL,
+                      "bwd_ls_pipeline": MAC_LS_PIPELINE_PER_EVAL, "bwd_ls_finish": MAC_LS_FINISH_PER_EVAL}
+            if name in ls_mac:
+                flops = (m_c + m_f) * 2 * ls_mac[name]
             if lvl:
                 m = m_c if lvl == "coarse" else m_f
                 if name.endswith("_fwd"):
@@ -400,9 +410,10 @@ def main():
             # layer-stationary backward: head (9 + 28 KiB), pipeline (reads 128 KiB of X + 16 of dy8, writes 128 of dy; the
             # dy reads behind the producer are served on chip), small problems (88 KiB)
             tile_bytes = {"_fwd": 167 * 1024, "_bwd_chain": (156 + 9) * 1024, "_bwd_weights": 344 * 1024,
-                          "bwd_ls": (37 + 272 + 88) * 1024}
+                          "bwd_ls": (30 + 272 + 88) * 1024, "bwd_ls_head": 30 * 1024, "bwd_ls_pipeline": 272 * 1024,
+                          "bwd_ls_finish": 88 * 1024}
             for name, v in timed.items():
-                m = m_c if name.startswith("coarse") else (m_c + m_f if name == "bwd_ls" else m_f)
+                m = m_c if name.startswith("coarse") else (m_c + m_f if name.startswith("bwd_ls") else m_f)
                 for suffix, b in tile_bytes.items():
                     if name.endswith(suffix):
                         v["GBps"] = round((m / 32) * b / (v["ms"] * 1e-3) / 1e9, 1)
@@ -412,6 +423,8 @@ def main():
                 pmc = os.path.join(ROOT, "profiles", cand)
                 if os.path.exists(pmc) and n == RAYS_PER_GPU:
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                    if traffic is None and dom == "bwd_ls_pipeline":
+                        traffic = json.load(open(pmc)).get("nerf_bwd_ls_kernel", {}).get("hbm_bytes_per_launch")
                     if traffic is not None:
                         traffic_source = (f"profiles/{cand}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
                                           "earlier run of this command (gfx950 FETCH x2 correction), NOT measured in "

@@ -379,18 +379,21 @@ int lnrf_nerf_mlp_bwd_weights(const lnrf_nerf_shape* shape, const void* save, vo
  * grads += d L / d params.  scratch: lnrf_nerf_bwd_ls_scratch_bytes(shape, m) bytes; the 32-bit word at byte offset
  * lnrf_nerf_bwd_ls_status_offset(shape, m) is non-zero after the launch if a bounded hand-off wait gave up (gradients of
  * that call are then invalid).  lnrf_nerf_mlp_bwd_ls2 runs two models (train.py:141-142: coarse and fine) in the same
- * persistent launch, pipelines shared in proportion to their evaluations. */
+ * persistent launch, pipelines shared in proportion to their evaluations.
+ * phases: 7 = the whole backward; a caller that wants to time the parts passes 1 (head launches), then 2 (the persistent
+ * pipeline launch), then 4 (small weight-gradient problems + folds) with the same arguments, in that order. */
 int64_t lnrf_nerf_bwd_ls_scratch_bytes(const lnrf_nerf_shape* shape, int64_t m);
 int64_t lnrf_nerf_bwd_ls_status_offset(const lnrf_nerf_shape* shape, int64_t m);
 int lnrf_nerf_mlp_bwd_ls(const lnrf_nerf_shape* shape, const void* packed, const void* save,
                          const float* density, const float* rgb, const float* g_density,
-                         const float* g_rgb, int64_t m, void* scratch, float* grads, lnrf_stream_t stream);
+                         const float* g_rgb, int64_t m, void* scratch, float* grads, int32_t phases,
+                         lnrf_stream_t stream);
 int lnrf_nerf_mlp_bwd_ls2(const lnrf_nerf_shape* shape, const void* packed_a, const void* save_a,
                           const float* density_a, const float* rgb_a, const float* g_density_a,
                           const float* g_rgb_a, int64_t m_a, void* scratch_a, float* grads_a,
                           const void* packed_b, const void* save_b, const float* density_b,
                           const float* rgb_b, const float* g_density_b, const float* g_rgb_b, int64_t m_b,
-                          void* scratch_b, float* grads_b, lnrf_stream_t stream);
+                          void* scratch_b, float* grads_b, int32_t phases, lnrf_stream_t stream);
 
 /* ---- fused spatial block of RefNERFModel (reference learn_nerf/ref_nerf.py:80-107; csrc/refnerf_fused.hip) ----
  * The spatial block of RefNERFModel is the NeRFModel trunk (Dense_0..8: 60 -> 256 x5, 316 -> 256, 256 x3, default

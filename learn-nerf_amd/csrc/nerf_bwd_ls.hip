@@ -533,7 +533,7 @@ struct LsModel {
 }  // namespace
 
 // head launch + pipeline launch (one or two models) + small problems + reduce launches
-static int ls_backward(const LsModel* mdl, int n_models, hipStream_t st) {
+static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t st) {
   int total = 0;
   int rc = ls_pipelines_for_device(&total);
   if (rc) return rc;
@@ -568,12 +568,16 @@ static int ls_backward(const LsModel* mdl, int n_models, hipStream_t st) {
     char* sc = (char*)md.scratch;
     unsigned* counters = reinterpret_cast<unsigned*>(sc + ls_dump_bytes(md.m) + ls_small_slab_bytes());
     float* slabs = reinterpret_cast<float*>(sc + ls_dump_bytes(md.m) + ls_small_slab_bytes() + ls_counter_bytes());
-    hipError_t e = hipMemsetAsync(counters, 0, ls_counter_bytes(), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
-    hipLaunchKernelGGL(nerf_bwd_head_kernel, dim3((unsigned)(n_tiles / kWaves)), dim3(kThreads),
-                       kRingBytes + round_up(kBiasFloats * 4, 1024), st, (const char*)md.packed, (const char*)md.save,
-                       md.density, md.rgb, md.g_density, md.g_rgb, md.m, n_tiles, sc);
-    LNRF_LAUNCH_CHECK();
+    if (phases & 1) {
+      hipLaunchKernelGGL(nerf_bwd_head_kernel, dim3((unsigned)(n_tiles / kWaves)), dim3(kThreads),
+                         kRingBytes + round_up(kBiasFloats * 4, 1024), st, (const char*)md.packed, (const char*)md.save,
+                         md.density, md.rgb, md.g_density, md.g_rgb, md.m, n_tiles, sc);
+      LNRF_LAUNCH_CHECK();
+    }
+    if (phases & 2) {
+      hipError_t e = hipMemsetAsync(counters, 0, ls_counter_bytes(), st);
+      if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
+    }
     LsJob& j = a.job[k];
     j.packed = (const char*)md.packed;
     j.save = (const char*)md.save;
@@ -585,9 +589,11 @@ static int ls_backward(const LsModel* mdl, int n_models, hipStream_t st) {
     j.pipelines = pipes[k];
   }
   if (n_models == 1) a.job[1] = a.job[0];
-  hipLaunchKernelGGL(nerf_bwd_ls_kernel, dim3((unsigned)(total * kLsStages)), dim3(kLsThreads), kLsLds, st, a);
-  LNRF_LAUNCH_CHECK();
-  for (int k = 0; k < n_models; ++k) {
+  if (phases & 2) {
+    hipLaunchKernelGGL(nerf_bwd_ls_kernel, dim3((unsigned)(total * kLsStages)), dim3(kLsThreads), kLsLds, st, a);
+    LNRF_LAUNCH_CHECK();
+  }
+  for (int k = 0; k < n_models && (phases & 4); ++k) {
     const LsModel& md = mdl[k];
     const int64_t n_tiles = nerf_tiles_for(md.m);
     // the five problems that are not a pipeline stage, fed by the dumps the two launches above left behind
@@ -626,7 +632,8 @@ static int ls_backward(const LsModel* mdl, int n_models, hipStream_t st) {
 
 extern "C" int lnrf_nerf_mlp_bwd_ls(const lnrf_nerf_shape* shape, const void* packed, const void* save,
                                     const float* density, const float* rgb, const float* g_density,
-                                    const float* g_rgb, int64_t m, void* scratch, float* grads, lnrf_stream_t stream) {
+                                    const float* g_rgb, int64_t m, void* scratch, float* grads, int32_t phases,
+                                    lnrf_stream_t stream) {
   if (!nerf_shape_fused(shape)) {
     set_error("lnrf_nerf_mlp_bwd_ls: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
     return LNRF_ERR_UNSUPPORTED;
@@ -634,8 +641,9 @@ extern "C" int lnrf_nerf_mlp_bwd_ls(const lnrf_nerf_shape* shape, const void* pa
   LNRF_CHECK_ARG(packed && save && density && rgb && g_density && g_rgb && scratch && grads, "null pointer");
   LNRF_CHECK_ARG(m >= 0, "bad m");
   if (m == 0) return LNRF_OK;
+  LNRF_CHECK_ARG(phases >= 1 && phases <= 7, "phases: bit 0 head, bit 1 pipeline, bit 2 small problems + fold");
   const LsModel md{packed, save, density, rgb, g_density, g_rgb, m, scratch, grads};
-  return ls_backward(&md, 1, as_stream(stream));
+  return ls_backward(&md, 1, phases, as_stream(stream));
 }
 
 extern "C" int lnrf_nerf_mlp_bwd_ls2(const lnrf_nerf_shape* shape, const void* packed_a, const void* save_a,
@@ -643,7 +651,7 @@ extern "C" int lnrf_nerf_mlp_bwd_ls2(const lnrf_nerf_shape* shape, const void* p
                                      const float* g_rgb_a, int64_t m_a, void* scratch_a, float* grads_a,
                                      const void* packed_b, const void* save_b, const float* density_b,
                                      const float* rgb_b, const float* g_density_b, const float* g_rgb_b, int64_t m_b,
-                                     void* scratch_b, float* grads_b, lnrf_stream_t stream) {
+                                     void* scratch_b, float* grads_b, int32_t phases, lnrf_stream_t stream) {
   if (!nerf_shape_fused(shape)) {
     set_error("lnrf_nerf_mlp_bwd_ls2: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
     return LNRF_ERR_UNSUPPORTED;
@@ -653,5 +661,6 @@ extern "C" int lnrf_nerf_mlp_bwd_ls2(const lnrf_nerf_shape* shape, const void* p
   LNRF_CHECK_ARG(m_a > 0 && m_b > 0, "both models need evaluations (use lnrf_nerf_mlp_bwd_ls for one)");
   const LsModel md[2] = {{packed_a, save_a, density_a, rgb_a, g_density_a, g_rgb_a, m_a, scratch_a, grads_a},
                          {packed_b, save_b, density_b, rgb_b, g_density_b, g_rgb_b, m_b, scratch_b, grads_b}};
-  return ls_backward(md, 2, as_stream(stream));
+  LNRF_CHECK_ARG(phases >= 1 && phases <= 7, "phases: bit 0 head, bit 1 pipeline, bit 2 small problems + fold");
+  return ls_backward(md, 2, phases, as_stream(stream));
 }

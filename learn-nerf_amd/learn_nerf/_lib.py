@@ -110,9 +110,9 @@ PROTOTYPES = {
     "lnrf_nerf_mlp_bwd_weights": (c_int32, [POINTER(NerfShape), _P, _P, c_int64, _P, _P]),
     "lnrf_nerf_bwd_ls_scratch_bytes": (c_int64, [POINTER(NerfShape), c_int64]),
     "lnrf_nerf_bwd_ls_status_offset": (c_int64, [POINTER(NerfShape), c_int64]),
-    "lnrf_nerf_mlp_bwd_ls": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_nerf_mlp_bwd_ls": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int32, _P]),
     "lnrf_nerf_mlp_bwd_ls2": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, _P, _P, c_int64, _P, _P,
-                                        _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+                                        _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int32, _P]),
     "lnrf_ngp_mlp_packed_bytes": (c_int64, [POINTER(NgpMlpDesc)]),
     "lnrf_ngp_mlp_scratch_bytes": (c_int64, [POINTER(NgpMlpDesc), c_int64]),
     "lnrf_ngp_mlp_pack": (c_int32, [POINTER(NgpMlpDesc), _P, _P, _P]),

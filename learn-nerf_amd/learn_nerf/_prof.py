@@ -17,6 +17,10 @@ def enable(flag: bool = True):
     _events.clear()
 
 
+def enabled() -> bool:
+    return _enabled
+
+
 @contextlib.contextmanager
 def section(name: str):
     if not _enabled:

@@ -24,7 +24,7 @@ ga, gb = torch.zeros_like(flat), torch.zeros_like(flat)
 args = (ctypes.byref(shape), L.ptr(ctx["packed"], torch.uint8), L.ptr(ctx["save"], torch.uint8), L.ptr(ctx["density"]),
         L.ptr(ctx["rgb"]), L.ptr(gd), L.ptr(gr), m)
 L.check(lib.lnrf_nerf_mlp_bwd(*args, L.ptr(sa, torch.uint8), L.ptr(ga), L.stream()), "bwd")
-L.check(lib.lnrf_nerf_mlp_bwd_ls(*args, L.ptr(sb, torch.uint8), L.ptr(gb), L.stream()), "bwd_ls")
+L.check(lib.lnrf_nerf_mlp_bwd_ls(*args, L.ptr(sb, torch.uint8), L.ptr(gb), 7, L.stream()), "bwd_ls")
 torch.cuda.synchronize()
 da = sa[:156 * n_tiles * 1024].view(n_tiles, 156, 1024).view(torch.int16)
 db = sb[:156 * n_tiles * 1024].view(n_tiles, 156, 1024).view(torch.int16)
