@@ -614,11 +614,12 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
       first += (int)nb;
       w.p[w.n_problems++] = p;
     };
-    add(170, 1, kSaveZ, kGradDy10m, 10, ROW_HIDDEN, 0, COL_DY10M, 1);      // Dense_10 rows 0..255 and Dense_9
-    add(130, 2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_256, 1);    // Dense_0
-    add(130, 2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, COL_256, 0);  // Dense_5 rows 256..315
-    add(46, 3, kSaveDin, kGradDy10m, 10, ROW_DEMB, 256, COL_DY10M, 0);     // Dense_10 rows 256..279
-    add(36, 4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);       // Dense_11
+    // workgroups in proportion to the bytes a problem streams per tile (26, 20, 20, 12, 10 KiB): 512 = two per CU
+    add(151, 1, kSaveZ, kGradDy10m, 10, ROW_HIDDEN, 0, COL_DY10M, 1);      // Dense_10 rows 0..255 and Dense_9
+    add(116, 2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_256, 1);    // Dense_0
+    add(116, 2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, COL_256, 0);  // Dense_5 rows 256..315
+    add(70, 3, kSaveDin, kGradDy10m, 10, ROW_DEMB, 256, COL_DY10M, 0);     // Dense_10 rows 256..279
+    add(59, 4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);       // Dense_11
     float* small_slabs = reinterpret_cast<float*>((char*)md.scratch + ls_dump_bytes(md.m));
     rc = launch_nerf_wgrad(w, first, md.save, md.scratch, n_tiles, md.grads, st, WgLayout{kSaveTileSlots, kGradTileSlots},
                            small_slabs, false);
