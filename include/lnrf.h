@@ -435,6 +435,22 @@ int lnrf_refnerf_dir_fwd(const void* packed, const float* dir_in, int64_t ld, in
 int lnrf_refnerf_dir_bwd(const void* packed, const void* dsave, const float* g_dir_out, int64_t m, void* scratch,
                          float* g_dir_in, int64_t ld, float* grads, lnrf_stream_t stream);
 
+/* Split-precision render path of RefNERFModel ("bf16x3": every forward WITHOUT a backward — rendering, evaluation,
+ * model.apply).  The reference evaluates ref_nerf.py:35-77 in fp32; here every fp32 operand of the trunk forward, the
+ * normal pass and the directional block is a bf16 pair hi + lo and every product is lo*hi + hi*lo + hi*hi on the bf16 MFMA
+ * with fp32 accumulation (~1e-5 of fp32), so that rendered RGB meets the 1e-3 gate on the fused path.
+ *   lnrf_refnerf_render_pack         fp32 parameters -> the split streams (lnrf_refnerf_render_packed_bytes bytes)
+ *   lnrf_refnerf_trunk_normal_split  spatial_out[m, 0:256] (fp32, `ld` floats per row) and n_raw[m, 3] = -d spatial_out[:, 0]
+ *                                    / dx in one launch; scratch: lnrf_refnerf_trunk_normal_split_scratch_bytes(m)
+ *   lnrf_refnerf_dir_fwd_split       dir_out[m, 3] from dir_in[m, 0:273] as lnrf_refnerf_dir_fwd, nothing saved */
+int64_t lnrf_refnerf_render_packed_bytes(void);
+int lnrf_refnerf_render_pack(const float* params, void* packed_split, lnrf_stream_t stream);
+int64_t lnrf_refnerf_trunk_normal_split_scratch_bytes(int64_t m);
+int lnrf_refnerf_trunk_normal_split(const void* packed_split, const float* x, int64_t m, float* spatial_out, int64_t ld,
+                                    float* n_raw, void* scratch, lnrf_stream_t stream);
+int lnrf_refnerf_dir_fwd_split(const void* packed_split, const float* dir_in, int64_t ld, int64_t m, float* dir_out,
+                               lnrf_stream_t stream);
+
 /* ------------------------------------------------------- data-parallel exchange ---- */
 
 /* One process per GPU; rays shard across ranks and the ONLY exchange of a training step is one all-reduce (sum) of

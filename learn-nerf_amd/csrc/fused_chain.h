@@ -277,6 +277,50 @@ __device__ __forceinline__ void chain_layer(RING& ring, Init init, GetB getb, Ep
   });
 }
 
+// ---- split precision ("bf16x3"): every fp32 operand is a bf16 pair hi = bf16(v), lo = bf16(v - hi) and every product is
+// lo*hi + hi*lo + hi*hi on the bf16 MFMA with fp32 accumulation.  The activations of a layer then need 2 x 64 VGPRs in
+// and 2 x 64 out, so these kernels run 4 waves per workgroup (one per SIMD, the whole 512-entry register file each).
+constexpr int kSplitWaves = 4;
+constexpr int kSplitThreads = kSplitWaves * 64;
+// v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
+template <int S, bool RELU>
+__device__ __forceinline__ void acc_to_frag_split(const f32x16& acc, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc[8 * S + j];
+    if (RELU) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
+    const __bf16 hb = (__bf16)v;
+    hi[j] = hb;
+    lo[j] = (__bf16)(v - (float)hb);
+  }
+}
+__device__ __forceinline__ void split_store(float v, bf16x8& hi, bf16x8& lo, int j) {
+  const __bf16 hb = (__bf16)v;
+  hi[j] = hb;
+  lo[j] = (__bf16)(v - (float)hb);
+}
+
+// one GEMM layer with split operands; C0 = consumption index (in hi/lo pairs) of the layer's first k-step
+template <int C0, int NK, int NO, class RING, class Init, class GetHi, class GetLo, class Epi>
+__device__ __forceinline__ void chain_layer_split(RING& ring, Init init, GetHi bhi, GetLo blo, Epi epi) {
+  static_for<NO>([&](auto o_) {
+    constexpr int o = decltype(o_)::value;
+    f32x16 acc = init(o_);
+    static_for<NK>([&](auto k_) {
+      constexpr int ks = decltype(k_)::value;
+      constexpr int c = 2 * (C0 + o * NK + ks);
+      const bf16x8 ahi = ring.template next<c>();
+      const bf16x8 alo = ring.template next<c + 1>();
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi(k_), acc, 0, 0, 0);  // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo(k_), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi(k_), acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    epi(o_, acc);
+  });
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // weight gradients
 // Backward, part 2: weight gradients  dW_l[in][out] += sum_m X_l[m][in] * dy_l[m][out]

@@ -213,51 +213,11 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
 // accumulation.  The activations of a layer therefore need 2 x 64 VGPRs in and 2 x 64 out: the workgroup is
 // 4 waves (one per SIMD) so that each wave may use the whole 512-entry register file.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSplitWaves = 4;
-constexpr int kSplitThreads = kSplitWaves * 64;
 constexpr int kFwd3Stages = kFwd3Frags / kStageFrags;  // 149
 struct Fwd3Seq {
   static constexpr int count = kFwd3Used;
   static constexpr int at(int c) { return fwd3_seq(c); }
 };
-
-// v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
-template <int S, bool RELU>
-__device__ __forceinline__ void acc_to_frag_split(const f32x16& acc, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = acc[8 * S + j];
-    if (RELU) v = __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
-    const __bf16 hb = (__bf16)v;
-    hi[j] = hb;
-    lo[j] = (__bf16)(v - (float)hb);
-  }
-}
-__device__ __forceinline__ void split_store(float v, bf16x8& hi, bf16x8& lo, int j) {
-  const __bf16 hb = (__bf16)v;
-  hi[j] = hb;
-  lo[j] = (__bf16)(v - (float)hb);
-}
-
-// one GEMM layer with split operands; C0 = consumption index (in hi/lo pairs) of the layer's first k-step
-template <int C0, int NK, int NO, class RING, class Init, class GetHi, class GetLo, class Epi>
-__device__ __forceinline__ void chain_layer_split(RING& ring, Init init, GetHi bhi, GetLo blo, Epi epi) {
-  static_for<NO>([&](auto o_) {
-    constexpr int o = decltype(o_)::value;
-    f32x16 acc = init(o_);
-    static_for<NK>([&](auto k_) {
-      constexpr int ks = decltype(k_)::value;
-      constexpr int c = 2 * (C0 + o * NK + ks);
-      const bf16x8 ahi = ring.template next<c>();
-      const bf16x8 alo = ring.template next<c + 1>();
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi(k_), acc, 0, 0, 0);  // small terms first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo(k_), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi(k_), acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    epi(o_, acc);
-  });
-}
 
 template <bool FROM_RAYS>
 __global__ __launch_bounds__(kSplitThreads) void nerf_fwd_split_kernel(

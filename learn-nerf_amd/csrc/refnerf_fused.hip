@@ -546,6 +546,320 @@ __global__ __launch_bounds__(kThreads) void refnerf_dir_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-precision render path ("bf16x3"; forwards without a backward: rendering, evaluation, model.apply).  The reference
+// runs ref_nerf.py:35-77 in fp32; plain bf16 operands leave the rendered colour up to 5e-2 off.  Here the trunk forward,
+// the normal pass and the directional block carry every fp32 operand as a bf16 pair (hi, lo) and form lo*hi + hi*lo +
+// hi*hi per product (fused_chain.h), as nerf_fwd_split_kernel does for NeRFModel.
+//   refnerf_render_split_kernel: trunk forward (spatial_out, fp32) and, with the ReLU masks kept in registers, the
+//                                normal pass n_raw = -d spatial_out[:, 0] / dx of the same tile — one launch, nothing saved
+//   refnerf_dir_fwd_split_kernel: Dense_10(relu(Dense_9([spatial_out, IDE, -d.n])))
+// Blob (lnrf_refnerf_render_pack): [hi, lo] pairs of the forward stream of Dense_0..8 | fp32 biases | pairs of the
+// normal-pass stream | pairs of the directional forward stream | its fp32 biases.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRef3FwdFrags = fwd3_base(9);
+constexpr int64_t kRef3FwdOff = 0;
+constexpr int64_t kRef3BiasOff = (int64_t)kRef3FwdFrags * kFragBytes;
+constexpr int64_t kRef3NrmOff = kRef3BiasOff + round_up(kBiasFloats * 4, 1024);
+constexpr int64_t kRef3DirOff = kRef3NrmOff + 2 * (int64_t)kNrmFrags * kFragBytes;
+constexpr int64_t kRef3DirBiasOff = kRef3DirOff + 2 * (int64_t)kDirFwdFrags * kFragBytes;
+constexpr int64_t kRef3Bytes = kRef3DirBiasOff + 1024;
+static_assert(kRef3FwdFrags % kStageFrags == 0 && (2 * kNrmFrags) % kStageFrags == 0 && (2 * kDirFwdFrags) % kStageFrags == 0,
+              "split streams are whole stages");
+struct RefFwd3Seq {
+  static constexpr int count = 2 * fwd_cons_base(9);
+  static constexpr int at(int c) { return fwd3_seq(c); }
+};
+struct DirFwd3Seq {
+  static constexpr int count = 160;
+  static constexpr int at(int c) { return 2 * dir_fwd_seq(c >> 1) + (c & 1); }
+};
+
+// 16 mask bits of one out tile: bit q set <=> accumulator register q is positive (the ReLU passes it)
+__device__ __forceinline__ unsigned acc_positive_bits(const f32x16& acc) {
+  unsigned bits = 0u;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bits |= (acc[q] > 0.0f ? 1u : 0u) << q;
+  return bits;
+}
+// dh * relu'(h) in split precision: registers 8S..8S+7 of the tile whose 16 mask bits start at bit `shift`
+template <int S>
+__device__ __forceinline__ void masked_frag_split(const f32x16& acc, unsigned bits, int shift, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split_store(((bits >> (shift + 8 * S + j)) & 1u) ? acc[8 * S + j] : 0.0f, hi, lo, j);
+}
+
+__global__ __launch_bounds__(kSplitThreads) void refnerf_render_split_kernel(
+    const char* __restrict__ packed3, const float* __restrict__ xin_g, int64_t M, float* __restrict__ zout, int64_t ldz,
+    float* __restrict__ nraw, uint4* __restrict__ mask_buf) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kSplitWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  {
+    const float* bias_g = reinterpret_cast<const float*>(packed3 + kRef3BiasOff);
+    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
+    for (int i = tid; i < kBiasFloats; i += kSplitThreads) bias_l[i] = bias_g[i];
+  }
+  float px[3] = {0, 0, 0};
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) px[a] = xin_g[m * 3 + a];
+  }
+  __syncthreads();
+  bf16x8 a0h[16], a0l[16], a1h[16], a1l[16];
+  // ReLU masks of h_0..h_7 of this wave's tile: written by the forward half, read back one layer ahead by the normal pass
+  // (8 KiB per tile in mask_buf: kept in registers they tip the kernel into 3.6 KB of scratch per lane)
+  uint4* my_masks = mask_buf + tile * (8 * 64) + lane;
+  {
+    // ---- trunk forward (model.py:50-56 as used by ref_nerf.py:92-99) ----
+    Ring<kRef3FwdFrags / kStageFrags, RefFwd3Seq, kSplitWaves> ring;
+    ring.stream = packed3 + kRef3FwdOff;
+    ring.wave = wave;
+    ring.lane = lane;
+    ring.prologue();
+    bf16x8 xe_hi[4], xe_lo[4];
+    static_for<4>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const int p = 4 * ks + pp;
+        float sn = 0.0f, co = 0.0f;
+        if (p < 15) {
+          const int pg = 15 * h + p;
+          const int cd = pg / 10, f = pg - 10 * cd;
+          const float v = cd == 0 ? px[0] : (cd == 1 ? px[1] : px[2]);
+          sincos_pe(v * (float)(1 << f), &sn, &co);
+        }
+        split_store(sn, xe_hi[ks], xe_lo[ks], 2 * pp);
+        split_store(co, xe_hi[ks], xe_lo[ks], 2 * pp + 1);
+      }
+    });
+    auto hidden = [&](auto s_, bf16x8(&inh)[16], bf16x8(&inl)[16], bf16x8(&outh)[16], bf16x8(&outl)[16]) {
+      constexpr int S = decltype(s_)::value;
+      unsigned mb[4] = {0u, 0u, 0u, 0u};
+      chain_layer_split<fwd_cons_base(S), fwd_nk(S), fwd_no(S)>(
+          ring, [&](auto o_) { return bias_acc(fwd_bias_base(S) + 32 * decltype(o_)::value, h); },
+          [&](auto k_) -> bf16x8 {
+            constexpr int ks = decltype(k_)::value;
+            if constexpr (S == 0) return xe_hi[ks];
+            else if constexpr (ks < 16) return inh[ks];
+            else return xe_hi[ks - 16];
+          },
+          [&](auto k_) -> bf16x8 {
+            constexpr int ks = decltype(k_)::value;
+            if constexpr (S == 0) return xe_lo[ks];
+            else if constexpr (ks < 16) return inl[ks];
+            else return xe_lo[ks - 16];
+          },
+          [&](auto o_, const f32x16& acc) {
+            constexpr int o = decltype(o_)::value;
+            acc_to_frag_split<0, true>(acc, outh[2 * o], outl[2 * o]);
+            acc_to_frag_split<1, true>(acc, outh[2 * o + 1], outl[2 * o + 1]);
+            mb[o >> 1] |= acc_positive_bits(acc) << (16 * (o & 1));
+          });
+      my_masks[S * 64] = make_uint4(mb[0], mb[1], mb[2], mb[3]);
+    };
+    hidden(std::integral_constant<int, 0>{}, a1h, a1l, a0h, a0l);
+    hidden(std::integral_constant<int, 1>{}, a0h, a0l, a1h, a1l);
+    hidden(std::integral_constant<int, 2>{}, a1h, a1l, a0h, a0l);
+    hidden(std::integral_constant<int, 3>{}, a0h, a0l, a1h, a1l);
+    hidden(std::integral_constant<int, 4>{}, a1h, a1l, a0h, a0l);
+    hidden(std::integral_constant<int, 5>{}, a0h, a0l, a1h, a1l);
+    hidden(std::integral_constant<int, 6>{}, a1h, a1l, a0h, a0l);
+    hidden(std::integral_constant<int, 7>{}, a0h, a0l, a1h, a1l);
+    // Dense_8: linear spatial_out (ref_nerf.py:98-99), fp32 rows of ldz floats
+    chain_layer_split<fwd_cons_base(8), fwd_nk(8), fwd_no(8)>(
+        ring, [&](auto o_) { return bias_acc(fwd_bias_base(8) + 32 * decltype(o_)::value, h); },
+        [&](auto k_) -> bf16x8 { return a1h[decltype(k_)::value]; },
+        [&](auto k_) -> bf16x8 { return a1l[decltype(k_)::value]; },
+        [&](auto o_, const f32x16& acc) {
+          constexpr int o = decltype(o_)::value;
+          if (valid) {
+            float* zr = zout + m * ldz + 32 * o + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(zr + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+          }
+        });
+  }
+  __syncthreads();  // every wave is done with the forward stream's ring slots
+  {
+    // ---- normal pass (ref_nerf.py:38-43): c_8 = -e_0, c_{l-1} = relu'(h_{l-1}) o (W_l^T c_l), into the embedding ----
+    Ring<2 * kNrmFrags / kStageFrags, LinSeq<2 * kNrmFrags>, kSplitWaves> ring;
+    ring.stream = packed3 + kRef3NrmOff;
+    ring.wave = wave;
+    ring.lane = lane;
+    ring.prologue();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      a1h[i] = zero_frag();
+      a1l[i] = zero_frag();
+    }
+    if (h == 0) a1h[0][0] = (__bf16)(-1.0f);
+    float nr[3] = {0.0f, 0.0f, 0.0f};
+    uint4 mk_next = my_masks[7 * 64];
+    auto back = [&](auto u_, auto l_, bf16x8(&inh)[16], bf16x8(&inl)[16], bf16x8(&outh)[16], bf16x8(&outl)[16]) {
+      constexpr int U = decltype(u_)::value, LL = decltype(l_)::value;  // stream layer, Dense index: out = c_{LL-1}
+      const uint4 mk = mk_next;
+      if constexpr (LL >= 2) mk_next = my_masks[(LL - 2) * 64];
+      chain_layer_split<nrm_base(U), 16, 8>(
+          ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return inh[decltype(k_)::value]; },
+          [&](auto k_) -> bf16x8 { return inl[decltype(k_)::value]; },
+          [&](auto o_, const f32x16& acc) {
+            constexpr int o = decltype(o_)::value;
+            const unsigned mb = mask_word(mk, o);
+            masked_frag_split<0>(acc, mb, 16 * (o & 1), outh[2 * o], outl[2 * o]);
+            masked_frag_split<1>(acc, mb, 16 * (o & 1), outh[2 * o + 1], outl[2 * o + 1]);
+          });
+    };
+    auto x_layer = [&](auto u_, bf16x8(&inh)[16], bf16x8(&inl)[16]) {
+      constexpr int U = decltype(u_)::value;
+      chain_layer_split<nrm_base(U), 16, 2>(
+          ring, [&](auto) { return zero_acc(); }, [&](auto k_) -> bf16x8 { return inh[decltype(k_)::value]; },
+          [&](auto k_) -> bf16x8 { return inl[decltype(k_)::value]; },
+          [&](auto o_, const f32x16& acc) {
+            float pl[3] = {px[0], px[1], px[2]};
+            asm volatile("" : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]));  // see refnerf_normal_kernel
+            emb_bwd_tile<decltype(o_)::value>(acc, pl, h, nr);
+          });
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    back(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, a1h, a1l, a0h, a0l);  // c_7
+    back(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{}, a0h, a0l, a1h, a1l);  // c_6
+    back(std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}, a1h, a1l, a0h, a0l);  // c_5
+    x_layer(std::integral_constant<int, 3>{}, a0h, a0l);                                           // x_emb rows of Dense_5
+    back(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, a0h, a0l, a1h, a1l);  // c_4
+    back(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, a1h, a1l, a0h, a0l);  // c_3
+    back(std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{}, a0h, a0l, a1h, a1l);  // c_2
+    back(std::integral_constant<int, 7>{}, std::integral_constant<int, 2>{}, a1h, a1l, a0h, a0l);  // c_1
+    back(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, a0h, a0l, a1h, a1l);  // c_0
+    x_layer(std::integral_constant<int, 9>{}, a1h, a1l);                                           // Dense_0^T on c_0
+#pragma unroll
+    for (int a = 0; a < 3; ++a) nr[a] += __shfl_xor(nr[a], 32, 64);
+    if (h == 0 && valid) {
+      nraw[m * 3 + 0] = nr[0];
+      nraw[m * 3 + 1] = nr[1];
+      nraw[m * 3 + 2] = nr[2];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kSplitThreads) void refnerf_dir_fwd_split_kernel(
+    const char* __restrict__ packed3, const float* __restrict__ dir_in, int64_t ld, int64_t M, float* __restrict__ dir_out) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kSplitWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  {
+    const float* bias_g = reinterpret_cast<const float*>(packed3 + kRef3DirBiasOff);
+    float* bias_l = reinterpret_cast<float*>(&smem[kBiasLdsOff]);
+    for (int i = tid; i < kDirBiasFloats; i += kSplitThreads) bias_l[i] = bias_g[i];
+  }
+  bf16x8 xh[18], xl[18];
+  static_for<18>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    float4 lo = make_float4(0, 0, 0, 0), hi = make_float4(0, 0, 0, 0);
+    if (valid) {
+      const float* row = dir_in + m * ld + 16 * ks + 4 * h;
+      if constexpr (ks < 17) {
+        lo = *reinterpret_cast<const float4*>(row);
+        hi = *reinterpret_cast<const float4*>(row + 8);
+      } else {
+        if (h == 0) lo.x = row[0];  // feature 272 = -d.n; 273.. do not exist
+      }
+    }
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_store(v[j], xh[ks], xl[ks], j);
+  });
+  __syncthreads();
+  Ring<2 * kDirFwdFrags / kStageFrags, DirFwd3Seq, kSplitWaves> ring;
+  ring.stream = packed3 + kRef3DirOff;
+  ring.wave = wave;
+  ring.lane = lane;
+  ring.prologue();
+  bf16x8 hh_[8], hl_[8];
+  chain_layer_split<0, 18, 4>(
+      ring, [&](auto o_) { return bias_acc(32 * decltype(o_)::value, h); },
+      [&](auto k_) -> bf16x8 { return xh[decltype(k_)::value]; }, [&](auto k_) -> bf16x8 { return xl[decltype(k_)::value]; },
+      [&](auto o_, const f32x16& acc) {
+        constexpr int o = decltype(o_)::value;
+        acc_to_frag_split<0, true>(acc, hh_[2 * o], hl_[2 * o]);
+        acc_to_frag_split<1, true>(acc, hh_[2 * o + 1], hl_[2 * o + 1]);
+      });
+  chain_layer_split<72, 8, 1>(
+      ring, [&](auto) { return bias_acc(128, h); }, [&](auto k_) -> bf16x8 { return hh_[decltype(k_)::value]; },
+      [&](auto k_) -> bf16x8 { return hl_[decltype(k_)::value]; },
+      [&](auto, const f32x16& acc) {
+        if (h == 0 && valid) {
+          dir_out[m * 3 + 0] = acc[0];
+          dir_out[m * 3 + 1] = acc[1];
+          dir_out[m * 3 + 2] = acc[2];
+        }
+      });
+}
+
+__global__ void refnerf_render_pack_kernel(const float* __restrict__ params, char* __restrict__ packed3) {
+  const int64_t n_f = (int64_t)kRef3FwdFrags * 512, n_n = 2 * (int64_t)kNrmFrags * 512, n_d = 2 * (int64_t)kDirFwdFrags * 512;
+  const int64_t total = n_f + kBiasFloats + n_n + n_d + kDirBiasFloats;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int idx = -1;
+    bool lo_part = false;
+    __bf16* dst = nullptr;
+    if (e < n_f) {  // pairs of the forward stream of Dense_0..8 (layout: nerf_layout.h fwd3_base)
+      const int g = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
+      int s = 0;
+      for (int i = 1; i < 9; ++i)
+        if (g >= fwd3_base(i)) s = i;
+      const int loc = g - fwd3_base(s);
+      if (loc < 2 * fwd_nk(s) * fwd_no(s)) idx = fwd_weight_index(s, (loc >> 1) / fwd_nk(s), (loc >> 1) % fwd_nk(s), lane, j);
+      lo_part = loc & 1;
+      dst = reinterpret_cast<__bf16*>(packed3 + kRef3FwdOff) + e;
+    } else if (e < n_f + kBiasFloats) {
+      const int i = (int)(e - n_f);
+      int s = 0;
+      for (int k = 1; k < kFwdLayers; ++k)
+        if (i >= fwd_bias_base(k)) s = k;
+      const int bi = s <= 8 ? fwd_bias_index(s, i - fwd_bias_base(s)) : -1;
+      reinterpret_cast<float*>(packed3 + kRef3BiasOff)[i] = bi >= 0 ? params[bi] : 0.0f;
+      continue;
+    } else if (e < n_f + kBiasFloats + n_n) {
+      const int64_t ee = e - n_f - kBiasFloats;
+      const int gg = (int)(ee >> 9), lane = (int)((ee >> 3) & 63), j = (int)(ee & 7);
+      const int g = gg >> 1;
+      int u = 0;
+      for (int i = 1; i < kNrmLayers; ++i)
+        if (g >= nrm_base(i)) u = i;
+      const int loc = g - nrm_base(u);
+      idx = nrm_weight_index(u, loc / nrm_nk(u), loc % nrm_nk(u), lane, j);
+      lo_part = gg & 1;
+      dst = reinterpret_cast<__bf16*>(packed3 + kRef3NrmOff) + ee;
+    } else if (e < n_f + kBiasFloats + n_n + n_d) {
+      const int64_t ee = e - n_f - kBiasFloats - n_n;
+      const int gg = (int)(ee >> 9), lane = (int)((ee >> 3) & 63), j = (int)(ee & 7);
+      idx = dir_fwd_weight_index(gg >> 1, lane, j);
+      lo_part = gg & 1;
+      dst = reinterpret_cast<__bf16*>(packed3 + kRef3DirOff) + ee;
+    } else {
+      const int i = (int)(e - n_f - kBiasFloats - n_n - n_d);
+      const int bi = dir_bias_index(i);
+      reinterpret_cast<float*>(packed3 + kRef3DirBiasOff)[i] = bi >= 0 ? params[bi] : 0.0f;
+      continue;
+    }
+    const float w = idx >= 0 ? params[idx] : 0.0f;
+    const __bf16 hi = (__bf16)w;
+    *dst = lo_part ? (__bf16)(w - (float)hi) : hi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // packing: the NeRFModel streams restricted to the trunk (head fragments zero) + the normal-pass stream
 // ---------------------------------------------------------------------------------------------
 __global__ void refnerf_pack_kernel(const float* __restrict__ params, char* __restrict__ packed) {
@@ -622,6 +936,51 @@ static int set_lds(K kernel, int bytes) {
   return LNRF_OK;
 }
 static inline dim3 tile_grid(int64_t n_tiles) { return dim3((unsigned)(n_tiles / kWaves)); }
+
+extern "C" int64_t lnrf_refnerf_render_packed_bytes(void) { return kRef3Bytes; }
+
+extern "C" int lnrf_refnerf_render_pack(const float* params, void* packed_split, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(params && packed_split, "null pointer");
+  hipLaunchKernelGGL(refnerf_render_pack_kernel, dim3(1024), dim3(256), 0, as_stream(stream), params, (char*)packed_split);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int64_t lnrf_refnerf_trunk_normal_split_scratch_bytes(int64_t m) {
+  if (m < 0) return -1;
+  const int64_t tiles = ((m + kTileCols - 1) / kTileCols + kSplitWaves - 1) / kSplitWaves * kSplitWaves;
+  return tiles * 8 * 64 * (int64_t)sizeof(uint4);
+}
+
+extern "C" int lnrf_refnerf_trunk_normal_split(const void* packed_split, const float* x, int64_t m, float* spatial_out,
+                                               int64_t ld, float* n_raw, void* scratch, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed_split && x && spatial_out && n_raw && scratch, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && ld >= 256 && ld % 4 == 0 && ((uintptr_t)spatial_out & 15) == 0,
+                 "spatial_out rows must be 16-byte aligned (ld a multiple of 4, >= 256)");
+  if (m == 0) return LNRF_OK;
+  int rc = set_lds(refnerf_render_split_kernel, kRefLds);
+  if (rc) return rc;
+  const int64_t tiles = (m + kTileCols - 1) / kTileCols;
+  hipLaunchKernelGGL(refnerf_render_split_kernel, dim3((unsigned)((tiles + kSplitWaves - 1) / kSplitWaves)),
+                     dim3(kSplitThreads), kRefLds, as_stream(stream), (const char*)packed_split, x, m, spatial_out, ld, n_raw,
+                     reinterpret_cast<uint4*>(scratch));
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
+
+extern "C" int lnrf_refnerf_dir_fwd_split(const void* packed_split, const float* dir_in, int64_t ld, int64_t m,
+                                          float* dir_out, lnrf_stream_t stream) {
+  LNRF_CHECK_ARG(packed_split && dir_in && dir_out, "null pointer");
+  LNRF_CHECK_ARG(m >= 0 && ld >= 273 && ld % 4 == 0 && ((uintptr_t)dir_in & 15) == 0, "dir_in rows must be 16-byte aligned");
+  if (m == 0) return LNRF_OK;
+  int rc = set_lds(refnerf_dir_fwd_split_kernel, kDirLds);
+  if (rc) return rc;
+  const int64_t tiles = (m + kTileCols - 1) / kTileCols;
+  hipLaunchKernelGGL(refnerf_dir_fwd_split_kernel, dim3((unsigned)((tiles + kSplitWaves - 1) / kSplitWaves)),
+                     dim3(kSplitThreads), kDirLds, as_stream(stream), (const char*)packed_split, dir_in, ld, m, dir_out);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
+}
 
 extern "C" int64_t lnrf_refnerf_trunk_packed_bytes(void) { return kRefPackBytes; }
 

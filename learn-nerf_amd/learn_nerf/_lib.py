@@ -94,6 +94,11 @@ PROTOTYPES = {
     "lnrf_refnerf_dir_scratch_bytes": (c_int64, [c_int64]),
     "lnrf_refnerf_dir_fwd": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P]),
     "lnrf_refnerf_dir_bwd": (c_int32, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P]),
+    "lnrf_refnerf_render_packed_bytes": (c_int64, []),
+    "lnrf_refnerf_render_pack": (c_int32, [_P, _P, _P]),
+    "lnrf_refnerf_trunk_normal_split_scratch_bytes": (c_int64, [c_int64]),
+    "lnrf_refnerf_trunk_normal_split": (c_int32, [_P, _P, c_int64, _P, c_int64, _P, _P, _P]),
+    "lnrf_refnerf_dir_fwd_split": (c_int32, [_P, _P, c_int64, c_int64, _P, _P]),
     "lnrf_nerf_param_count": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_packed_bytes": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_save_bytes": (c_int64, [POINTER(NerfShape), c_int64]),

@@ -68,6 +68,10 @@ class RefNERFModel(RefNERFBase):
     precision: str = "bf16"  # operands of the Dense layers: "bf16" (MFMA rate) | "fp32" (exact, parity gate)
     tag: str = "refnerf"
     spatial_kernel: str = "fused"  # bf16 + default widths: "fused" chain kernels | "dense" GEMM path
+    # fused path, forward without a backward (rendering, evaluation, model.apply): "bf16x3" = split-precision kernels
+    # (lnrf_refnerf_trunk_normal_split / _dir_fwd_split: the reference's fp32 arithmetic to ~1e-5) | "bf16" = the training
+    # forward's plain bf16 operands
+    render_precision: str = "bf16x3"
 
     _pack_cache: Any = field(default=None, repr=False, compare=False)
     _pack_generation: int = field(default=0, repr=False, compare=False)
@@ -84,21 +88,27 @@ class RefNERFModel(RefNERFBase):
         """the fused directional-block kernels cover the reference's widths: 256 + 4^2 + 1 -> 128 -> 3"""
         return self.sh_degree == 4 and self.color_layer_dim == 128
 
-    def packed_trunk(self, flat: torch.Tensor) -> torch.Tensor:
-        """Fragment streams of Dense_0..8 for the fused trunk kernels; same cache discipline as
+    def packed_trunk(self, flat: torch.Tensor, kind: str = "bf16") -> torch.Tensor:
+        """Fragment streams for the fused kernels ("bf16": trunk, normal pass and directional block, forward and transposed;
+        "split": hi/lo pairs of the forward-only streams for the render kernels); same cache discipline as
         NeRFModel.packed_weights (fresh buffer per miss, entries keep their source tensor alive)."""
         if self._pack_cache is None:
             self._pack_cache = OrderedDict()
-        key = (flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
+        key = (kind, flat.data_ptr(), flat.numel(), flat._version, str(flat.device), self._pack_generation)
         hit = self._pack_cache.get(key)
         if hit is not None:
             self._pack_cache.move_to_end(key)
             return hit[1]
-        packed = torch.empty(L.lib().lnrf_refnerf_trunk_packed_bytes(), dtype=torch.uint8, device=flat.device)
-        L.check(L.lib().lnrf_refnerf_trunk_pack(L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
-                "refnerf_trunk_pack")
+        if kind == "split":
+            packed = torch.empty(L.lib().lnrf_refnerf_render_packed_bytes(), dtype=torch.uint8, device=flat.device)
+            L.check(L.lib().lnrf_refnerf_render_pack(L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
+                    "refnerf_render_pack")
+        else:
+            packed = torch.empty(L.lib().lnrf_refnerf_trunk_packed_bytes(), dtype=torch.uint8, device=flat.device)
+            L.check(L.lib().lnrf_refnerf_trunk_pack(L.ptr(flat), L.ptr(packed, torch.uint8), L.stream()),
+                    "refnerf_trunk_pack")
         self._pack_cache[key] = (flat, packed)
-        while len(self._pack_cache) > 4:
+        while len(self._pack_cache) > 6:
             self._pack_cache.popitem(last=False)
         return packed
 
@@ -140,7 +150,36 @@ class RefNERFModel(RefNERFBase):
         return out
 
     # ---- fused spatial block ---------------------------------------------------------------------------
+    def _render_forward_points(self, flat, x, d):
+        """Forward without a backward on the split-precision kernels (render_precision "bf16x3")."""
+        lib = L.lib()
+        m, dev, hd = x.shape[0], flat.device, self.hidden_dim
+        ne = self.sh_degree ** 2
+        packed3 = self.packed_trunk(flat, "split")
+        width = hd + ne + 1
+        ld = (width + 3) // 4 * 4
+        dir_full = torch.empty((m, ld), dtype=F32, device=dev)
+        dir_in = dir_full[:, :width]
+        nraw = torch.empty((m, 3), dtype=F32, device=dev)
+        lease = _ws.lease("ref_masks", lib.lnrf_refnerf_trunk_normal_split_scratch_bytes(m), dev)
+        with _prof.section(f"{self.tag}_spatial_fwd_split"):
+            L.check(lib.lnrf_refnerf_trunk_normal_split(L.ptr(packed3, torch.uint8), L.ptr(x), m, L.ptr(dir_full), ld,
+                                                        L.ptr(nraw), L.ptr(lease.buf, torch.uint8), L.stream()),
+                    "refnerf_trunk_normal_split")
+        lease.release()
+        with _prof.section(f"{self.tag}_head_fwd"):
+            density, diffuse, spectral, aux2 = ops.refnerf_head_fwd(dir_in, nraw, d, self.sh_degree, dir_in[:, hd:])
+            dir_out = torch.empty((m, 3), dtype=F32, device=dev)
+            L.check(lib.lnrf_refnerf_dir_fwd_split(L.ptr(packed3, torch.uint8), L.ptr(dir_full), ld, m, L.ptr(dir_out),
+                                                   L.stream()), "refnerf_dir_fwd_split")
+            rgb = ops.refnerf_color_fwd(dir_out, spectral, diffuse)
+        return density, rgb, dict(normal_mse=aux2[:, 0], neg_normal=aux2[:, 1]), None
+
     def _fused_forward_points(self, flat, x, d, save: bool):
+        if self.render_precision not in ("bf16x3", "bf16"):
+            raise ValueError(f"unknown render_precision {self.render_precision!r}")
+        if not save and self.render_precision == "bf16x3" and self._use_fused_dir():
+            return self._render_forward_points(flat, x, d)
         lib = L.lib()
         W = self._views(flat)
         m, dev, hd = x.shape[0], flat.device, self.hidden_dim

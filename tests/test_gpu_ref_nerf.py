@@ -206,6 +206,80 @@ def test_ref_nerf_bf16_paths(kw, m):
     assert rel < 3e-2
 
 
+@pytest.mark.parametrize("m", [500, 5000, 70000])
+def test_ref_nerf_split_forward_matches_exact(m):
+    """The split-precision render kernels (lnrf_refnerf_trunk_normal_split / lnrf_refnerf_dir_fwd_split: bf16 hi + lo operand
+    pairs, three MFMAs per product) — what every forward WITHOUT a backward runs on the default fused configuration —
+    against the EXACT float64 model (ref_nerf.py:35-77 restated in oracle/ref_nerf.py): rgb 2e-4, density 1e-4 relative;
+    the per-sample normal losses as for the exact-fp32 path (ratios of fp32 input gradients: 2e-3, gated at the 99th
+    percentile because unit normals of near-zero gradients flip under any rounding)."""
+    model, params, flat = make_model(precision="bf16")
+    assert model._use_fused_trunk() and model.render_precision == "bf16x3"
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(m, 3, generator=gen) * 2 - 1).float()
+    d = unit(m, seed=9)
+    dens, rgb, aux = model.apply(dict(params=params), x.cuda(), d.cuda())
+    okw = dict(sh_degree=model.sh_degree, hidden_dim=model.hidden_dim, color_layer_dim=model.color_layer_dim)
+    ed, er, eaux = ORF.ref_nerf_model(flat.cpu().double(), x.double(), d.double(), **okw)
+    e_rgb = (rgb.cpu().double() - er).abs().max().item()
+    e_den = ((dens.cpu().double() - ed).abs() / (1 + ed.abs())).max().item()
+    aux_err = torch.cat([(aux[k].cpu().double() - eaux[k]).abs().reshape(-1) for k in aux])
+    q_aux = torch.quantile(aux_err[:100000], 0.99).item()
+    print(f"ref-nerf split-precision forward m={m}: rgb {e_rgb:.2e}, density {e_den:.2e}, aux p99 {q_aux:.2e} max "
+          f"{aux_err.max().item():.2e} vs exact")
+    assert dens.shape == (m, 1) and set(aux) == {"normal_mse", "neg_normal"}
+    assert e_rgb < 2e-4 and e_den < 1e-4 and q_aux < 2e-3
+
+
+def test_ref_nerf_renderer_meets_the_1e3_gate_on_the_fused_path():
+    """north_star: rendered RGB within 1e-3 of the reference's fp32 arithmetic on identical rays.  NeRFRenderer over two
+    RefNERFModels in their DEFAULT configuration (precision "bf16": fused kernels; the renderer's forwards carry no backward
+    and run the split-precision kernels) at 256 rays x (64 + 128) samples against the exact float64 oracle."""
+    from learn_nerf.ref_nerf import RefNERFModel
+    from learn_nerf.render import NeRFRenderer
+    from learn_nerf.rng import Key, split
+    from learn_nerf.train import TrainLoop
+    from oracle import philox
+    from oracle import render as OR
+
+    n, tc, tf = 256, 64, 128
+    loop = TrainLoop(RefNERFModel(), RefNERFModel(), init_rng=8, lr=1e-3, coarse_ts=tc, fine_ts=tf)
+    for sl in loop._slices(loop.flat)[:2]:
+        # density = exp(spatial_out[:, 0]): lift Dense_8's bias[0] so that some rays are opaque and compositing matters
+        off = 0
+        for i, (fi, fo) in enumerate(loop.coarse.layer_dims()):
+            off += fi * fo
+            if i == 8:
+                sl[off] += 1.0
+            off += fo
+    loop._params_changed()
+    gen = torch.Generator().manual_seed(0)
+    o = torch.randn(n, 3, generator=gen)
+    o = 4 * o / o.norm(dim=-1, keepdim=True)
+    dd = -o + (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+    dd = dd / dd.norm(dim=-1, keepdim=True)
+    rays = torch.stack([o, dd], 1).float().contiguous()
+    p = loop.state.params
+    renderer = NeRFRenderer(coarse=loop.coarse, fine=loop.fine, coarse_params=p["coarse"], fine_params=p["fine"],
+                            background=p["background"], bbox_min=(-1.0,) * 3, bbox_max=(1.0,) * 3, coarse_ts=tc,
+                            fine_ts=tf)
+    key = Key(99)
+    out = renderer.render_rays(key, rays.cuda())
+    ck, fk = split(key, 2)
+    uc = torch.from_numpy(philox.ray_uniforms(ck.seed, 0, 0, n, tc)).double()
+    uf = torch.from_numpy(philox.ray_uniforms(fk.seed, 1, 0, n, tf)).double()
+    cf, ff, bg = [t.cpu().double() for t in loop._slices(loop.flat)]
+    mk = lambda fl: (lambda x, d: ORF.ref_nerf_model(fl, x, d, sh_degree=4))
+    ref = OR.render_hierarchy(mk(cf), mk(ff), bg, torch.tensor([-1.0] * 3, dtype=F64), torch.tensor([1.0] * 3, dtype=F64),
+                              rays.double(), tc, tf, uc, uf)
+    for lvl in ("coarse", "fine"):
+        err = (out[lvl]["outputs"].cpu().double() - ref[lvl]["outputs"]).abs().max().item()
+        aerr = (out[lvl]["alphas"].cpu().double() - ref[lvl]["alphas"]).abs().max().item()
+        print(f"ref-nerf renderer {lvl}: rgb max|d| vs exact oracle {err:.2e}, alpha {aerr:.2e}")
+        assert err < 1e-3 and aerr < 1e-3
+    assert ref["fine"]["alphas"].max() > 0.5, "the test scene must have opaque rays"
+
+
 def test_dense_precision_switch_is_scoped():
     from learn_nerf import _lib as L
     from learn_nerf import ops
