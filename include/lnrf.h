@@ -245,9 +245,13 @@ int lnrf_hashgrid_bwd(const lnrf_hashgrid_desc* desc, const float* x, int64_t m,
 /* Same scatter with caller-provided scratch (lnrf_hashgrid_bwd_scratch_bytes): hashed levels are reduced
  * without global float atomics (bin by 8K-entry table slice, then one workgroup per bucket accumulates in
  * LDS).  u == NULL: value weights (first-order gradient); u [M,3]: derivative weights (see bwd_dir).
- * level_absmax (optional, u == NULL only): n_levels floats, level_absmax[l] >= max |g_enc_t rows 2l, 2l+1| — the
- * scale of the pass's fixed-point tuples; lnrf_ngp_mlp_bwd produces it while writing g_enc_t.  NULL: found by a
- * pass over g_enc_t.  A bound that is too small wraps the fixed-point values (caller error).
+ * level_absmax (optional, u == NULL only): n_levels floats, level_absmax[l] >= max |g_enc_t rows 2l, 2l+1|;
+ * lnrf_ngp_mlp_bwd produces it while writing g_enc_t.  WITH it the contributions are binned as 26-bit fixed point of
+ * that bound (8-byte tuples: resolution 2^-25 of the level's bound per contribution — a QUANTISED scatter, the fused
+ * bf16 path's; values beyond a too-small bound saturate).  NULL: 12-byte fp32 tuples, the level maximum is found while
+ * binning and the reduce pass sums in 64-bit fixed point at 2^-46 of it per contribution — the exact-fp32 path's
+ * scatter (instant_ngp.py:211-224 under jax.grad).  Either way NaN / Inf contributions reach the table through float
+ * atomics, as a floating-point scatter-add would propagate them.
  * scratch == NULL falls back to the LDS-sliced / atomic kernels. */
 int64_t lnrf_hashgrid_bwd_scratch_bytes(const lnrf_hashgrid_desc* desc, int64_t m);
 int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const float* x, const float* u, int64_t m,
@@ -409,7 +413,8 @@ int lnrf_nerf_mlp_bwd_ls2(const lnrf_nerf_shape* shape, const void* packed_a, co
  *                               (first-order path; scratch: lnrf_nerf_bwd_scratch_bytes)
  *   lnrf_refnerf_normal_bwd     grads += the second-order term: d L / d Dense_0..8 through n_raw, given
  *                               u = d L / d n_raw [m, 3] (jax.grad of a function that calls jax.grad, train.py:89-90
- *                               over ref_nerf.py:42; scratch: lnrf_nerf_save_bytes)
+ *                               over ref_nerf.py:42; scratch: lnrf_nerf_save_bytes; the slab region behind the chain
+ *                               states in cdump is used as workspace for the fixed-order weight-gradient fold)
  * Head, integrated directional encoding and the 273 -> 128 -> 3 directional block: lnrf_refnerf_head_*,
  * lnrf_refnerf_color_*, lnrf_dense_*. */
 int64_t lnrf_refnerf_trunk_packed_bytes(void);

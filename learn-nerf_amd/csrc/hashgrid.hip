@@ -328,7 +328,7 @@ struct BucketTuple {
   float v0, v1;
 };
 // Plain scatter (u == nullptr): the trilinear weights are <= 1, so every contribution is bounded by the level's
-// max |d loss / d enc|, which a small pre-pass (level_absmax_kernel) provides BEFORE binning.  The values are then
+// max |d loss / d enc|, which the producer of the gradient rows hands in (lnrf_ngp_mlp_bwd).  The values are then
 // quantised right away to 26-bit fixed point relative to that bound (2^-25 of the level maximum, about fp32's own
 // resolution at the maximum) and a tuple is 8 bytes: {q0 : 26 | rel[0:6], q1 : 26 | rel[6:12]} — a third less tuple
 // traffic than {rel, float, float}, integer sums in the reduce pass without any floating-point conversion.
@@ -337,7 +337,10 @@ struct PackedTuple {
 };
 constexpr int kQuantBits = 26;
 __device__ __forceinline__ PackedTuple pack_tuple(unsigned rel, float v0, float v1, float scale) {
-  const int q0 = __float2int_rn(v0 * scale), q1 = __float2int_rn(v1 * scale);
+  // saturate (a caller-supplied bound that is too small must not wrap through the 26-bit field into the other sign)
+  constexpr float kQmax = (float)((1 << (kQuantBits - 1)) - 1);
+  const int q0 = __float2int_rn(fminf(fmaxf(v0 * scale, -kQmax), kQmax));
+  const int q1 = __float2int_rn(fminf(fmaxf(v1 * scale, -kQmax), kQmax));
   PackedTuple t;
   t.w0 = ((unsigned)q0 & 0x03FFFFFFu) | ((rel & 63u) << 26);
   t.w1 = ((unsigned)q1 & 0x03FFFFFFu) | ((rel >> 6) << 26);
@@ -377,20 +380,6 @@ __device__ __forceinline__ unsigned run_reserve(unsigned* counter, unsigned b, b
   return base + (unsigned)(lane - hl);
 }
 
-// max |g| over the two feature rows of every bucketed level: level_max[level] (float bits; zeroed by the caller)
-__global__ void level_absmax_kernel(BucketPlan plan, const float* __restrict__ g_enc_t, int64_t M,
-                                    unsigned* __restrict__ level_max) {
-  const int li = blockIdx.y;
-  const float* __restrict__ g = g_enc_t + (int64_t)(2 * plan.level[li]) * M;  // two consecutive rows of M floats
-  float vmax = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * M; i += (int64_t)gridDim.x * blockDim.x)
-    vmax = fmaxf(vmax, fabsf(g[i]));
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-  // non-negative floats order like their bit patterns
-  if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&level_max[plan.level[li]], __float_as_uint(vmax));
-}
-
 template <bool QUANT>
 __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float* __restrict__ x,
                                     const float* __restrict__ u, int64_t M, const float* __restrict__ g_enc_t,
@@ -404,7 +393,7 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
   const int G = d.grid_size[level], T = d.table_size[level], hashed = d.hashed[level];
   BucketTuple* __restrict__ tup = tuples + plan.tuple_off[li];
   PackedTuple* __restrict__ ptup = reinterpret_cast<PackedTuple*>(tuples) + plan.tuple_off[li];
-  float qscale = 0.0f;  // QUANT: 2^(25 - e) with level max < 2^e (level_absmax_kernel ran before this launch)
+  float qscale = 0.0f;  // QUANT: 2^(25 - e) with the caller's bound < 2^e
   if (QUANT) {
     int e = 0;
     frexpf(__uint_as_float(level_max[plan.level[li]]), &e);
@@ -468,21 +457,27 @@ __global__ void hashgrid_bin_kernel(HashGridDesc d, BucketPlan plan, const float
       const unsigned off = hashed ? (valid ? atomicAdd(&s_count[b], 1u) : 0u) : run_reserve(s_count, b, valid);
       if (valid) {
         const long long pos = (long long)s_base[b] + off;
-        if (!QUANT) vmax = fmaxf(vmax, fmaxf(fabsf(w * g0), fabsf(w * g1)));
+        // NaN / Inf contributions cannot be carried in fixed point: they take the float atomics below, which propagate
+        // them into the table as the reference's scatter-add would, and their tuple slot carries zeros
+        const float v0 = w * g0, v1 = w * g1;
+        const bool finite = fabsf(v0) <= 3.0e38f && fabsf(v1) <= 3.0e38f;
+        const float t0 = finite ? v0 : 0.0f, t1 = finite ? v1 : 0.0f;
+        if (!QUANT) vmax = fmaxf(vmax, fmaxf(fabsf(t0), fabsf(t1)));
         if (pos < cap) {
           if (QUANT) {
-            ptup[(long long)b * cap + pos] = pack_tuple(idx - b * kBucketEntries, w * g0, w * g1, qscale);
+            ptup[(long long)b * cap + pos] = pack_tuple(idx - b * kBucketEntries, t0, t1, qscale);
           } else {
             BucketTuple t;
             t.rel = idx - b * kBucketEntries;
-            t.v0 = w * g0;
-            t.v1 = w * g1;
+            t.v0 = t0;
+            t.v1 = t1;
             tup[(long long)b * cap + pos] = t;
           }
-        } else {  // bucket full: rare, stay correct
+        }
+        if (pos >= cap || !finite) {  // bucket full (rare), or a non-finite value
           float* gt = g_tables + d.table_offset[level] + 2 * (int64_t)idx;
-          atomicAdd(gt, w * g0);
-          atomicAdd(gt + 1, w * g1);
+          atomicAdd(gt, v0);
+          atomicAdd(gt + 1, v1);
         }
       }
     }
@@ -831,23 +826,19 @@ extern "C" int lnrf_hashgrid_bwd_bucketed(const lnrf_hashgrid_desc* desc, const 
     hipError_t e = hipMemsetAsync(cursors, 0, (size_t)cursor_bytes, as_stream(stream));
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(bucket cursors)");
     const unsigned chunks = (unsigned)((m + kBinChunk - 1) / kBinChunk);
-    if (u == nullptr) {
-      // weights <= 1: quantised 8-byte tuples against the level's max |g| — handed in by the producer of g_enc_t
-      // (lnrf_ngp_mlp_bwd finds it while it writes the rows) or found first by a pass of its own
-      if (level_absmax) {
-        level_max = reinterpret_cast<unsigned*>(const_cast<float*>(level_absmax));  // read only from here on
-      } else {
-        hipLaunchKernelGGL(level_absmax_kernel, dim3(256, (unsigned)plan.n), dim3(256), 0, as_stream(stream), plan,
-                           g_enc_t, m, level_max);
-        LNRF_LAUNCH_CHECK();
-      }
+    if (u == nullptr && level_absmax != nullptr) {
+      // the caller hands in a bound of |g| per level (lnrf_ngp_mlp_bwd finds it while it writes the rows; weights <= 1):
+      // quantised 8-byte tuples, 2^-25 of that bound per contribution.  This is the fused bf16 path's scatter; WITHOUT a
+      // bound (the exact-fp32 path, any other caller) the fp32-tuple form below is used: 12-byte tuples, level maximum
+      // found while binning, 64-bit fixed point of 2^-46 of the maximum per contribution in the reduce pass.
+      level_max = reinterpret_cast<unsigned*>(const_cast<float*>(level_absmax));  // read only from here on
       hipLaunchKernelGGL(hashgrid_bin_kernel<true>, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d,
                          plan, x, u, m, g_enc_t, tuples, cursors, level_max, g_tables);
       LNRF_LAUNCH_CHECK();
       hipLaunchKernelGGL(hashgrid_reduce_kernel<true>, dim3((unsigned)plan.wg_off[plan.n]), dim3(kReduceThreads),
                          64 * 1024, as_stream(stream), d, plan, tuples, cursors, level_max, g_tables);
     } else {
-      // directional-derivative weights are unbounded: fp32 tuples, level maximum found while binning
+      // no bound handed in, or directional-derivative weights (unbounded): fp32 tuples, level maximum found while binning
       hipLaunchKernelGGL(hashgrid_bin_kernel<false>, dim3(chunks, (unsigned)plan.n), dim3(256), 0, as_stream(stream), d,
                          plan, x, u, m, g_enc_t, tuples, cursors, level_max, g_tables);
       LNRF_LAUNCH_CHECK();

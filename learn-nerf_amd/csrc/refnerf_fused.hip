@@ -1021,7 +1021,9 @@ extern "C" int lnrf_refnerf_normal_pass(const void* packed, const void* save, co
 }
 
 // the ten weight-gradient problems of the trunk: Dense_1..8 (hidden x hidden), Dense_0 and the x_emb rows of Dense_5
-static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int do_bias, float* grads, hipStream_t st) {
+// `slabs`: room for 512 workgroups' partial sums (kSlabBlockBytes each) — the deterministic epilogue of fused_chain.h
+static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int do_bias, float* grads, hipStream_t st,
+                       float* slabs) {
   WgradArgs a;
   a.n_problems = 0;
   int first = 0;
@@ -1041,7 +1043,12 @@ static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int 
   for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, do_bias, 56);
   add(2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, do_bias, 32);
   add(2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, 0, 32);
-  return launch_nerf_wgrad(a, first, xbuf, ybuf, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots});
+  return launch_nerf_wgrad(a, first, xbuf, ybuf, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots},
+                           first <= 512 ? slabs : nullptr);
+}
+// the slab region behind a gradient dump that was sized by lnrf_nerf_bwd_scratch_bytes
+static float* slabs_behind_dump(const void* dump, int64_t n_tiles) {
+  return reinterpret_cast<float*>(const_cast<char*>(reinterpret_cast<const char*>(dump)) + (int64_t)kGradSlots * n_tiles * kFragBytes);
 }
 
 extern "C" int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, const float* g_spatial, int64_t ld,
@@ -1056,7 +1063,7 @@ extern "C" int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, cons
   hipLaunchKernelGGL(refnerf_trunk_bwd_chain_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
                      (const char*)packed, (const char*)save, g_spatial, ld, m, n_tiles, (char*)scratch);
   LNRF_LAUNCH_CHECK();
-  return trunk_wgrad(save, scratch, n_tiles, 1, grads, as_stream(stream));
+  return trunk_wgrad(save, scratch, n_tiles, 1, grads, as_stream(stream), slabs_behind_dump(scratch, n_tiles));
 }
 
 extern "C" int lnrf_refnerf_normal_bwd(const void* packed, const void* save, const void* cdump, const float* x,
@@ -1070,11 +1077,14 @@ extern "C" int lnrf_refnerf_normal_bwd(const void* packed, const void* save, con
   hipLaunchKernelGGL(refnerf_tangent_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
                      (const char*)packed, (const char*)save, x, u, m, n_tiles, (char*)scratch);
   LNRF_LAUNCH_CHECK();
-  return trunk_wgrad(scratch, cdump, n_tiles, 0, grads, as_stream(stream));
+  // the partial sums go behind the chain-state dump (cdump is sized by lnrf_nerf_bwd_scratch_bytes: dump + slab region)
+  return trunk_wgrad(scratch, cdump, n_tiles, 0, grads, as_stream(stream), slabs_behind_dump(cdump, n_tiles));
 }
 
 extern "C" int64_t lnrf_refnerf_dir_save_bytes(int64_t m) { return (int64_t)kDirSaveSlots * nerf_tiles_for(m) * kFragBytes; }
-extern "C" int64_t lnrf_refnerf_dir_scratch_bytes(int64_t m) { return (int64_t)kDirGradSlots * nerf_tiles_for(m) * kFragBytes; }
+extern "C" int64_t lnrf_refnerf_dir_scratch_bytes(int64_t m) {  // gradient dump, then the slab region of the weight-gradient launch
+  return (int64_t)kDirGradSlots * nerf_tiles_for(m) * kFragBytes + 512 * kSlabBlockBytes;
+}
 
 extern "C" int lnrf_refnerf_dir_fwd(const void* packed, const float* dir_in, int64_t ld, int64_t m, void* dsave,
                                     float* dir_out, lnrf_stream_t stream) {
@@ -1122,6 +1132,7 @@ extern "C" int lnrf_refnerf_dir_bwd(const void* packed, const void* dsave, const
   };
   add(5, kDirSaveXin, kDirGradDy9, kDirHidden, kDirIn, kDirW9, kDirB9, 400);
   add(4, kDirSaveH, kDirGradDy10, 3, kDirHidden, kDirW10, kDirB10, 112);
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (int64_t)kDirGradSlots * n_tiles * kFragBytes);
   return launch_nerf_wgrad(a, first, dsave, scratch, n_tiles, grads, as_stream(stream),
-                           WgLayout{kDirSaveTileSlots, kDirGradTileSlots});
+                           WgLayout{kDirSaveTileSlots, kDirGradTileSlots}, first <= 512 ? slabs : nullptr);
 }

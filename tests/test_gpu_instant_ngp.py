@@ -452,3 +452,95 @@ def test_ngp_ref_nerf_bf16_dense_path():
     print(f"ngp-ref bf16: rgb {e_rgb:.2e} vs bf16-operand oracle, {x_rgb:.2e} vs exact")
     assert e_rgb < 4e-3 and x_rgb < 5e-2
     assert ((dens.reshape(-1).cpu() - rd.detach()[:, 0]).abs() / (1 + rd.detach()[:, 0].abs())).max().item() < 4e-3
+
+
+def _scatter_case(m=20000, seed=3, decades=12):
+    """Points on the lattice k / 1024 of the unit box: cell coordinates (G - 1) * x are exact in fp32, so the device's
+    trilinear weights equal the float64 oracle's to a few 1e-8 relative and the comparison is about the SUMMATION."""
+    from learn_nerf.instant_ngp import MultiresHashTableEncoding
+
+    ts, gs = [2 ** 12] * 4, [8, 16, 32, 64]
+    lo, hi = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    enc = MultiresHashTableEncoding(ts, gs, lo, hi, 2, False)
+    gen = torch.Generator().manual_seed(seed)
+    x = (torch.randint(0, 1025, (m, 3), generator=gen).float() / 1024.0).contiguous()
+    # per-sample magnitudes spread over `decades` decades: the entries of a table then see sums from 1e-12 to 1
+    mag = 10.0 ** (-decades * torch.rand(m, 1, generator=gen))
+    g_enc = (torch.randn(m, 2 * len(gs), generator=gen) * mag).float()
+
+    def scatter64(g):
+        t64 = torch.zeros(enc.num_table_floats(), dtype=F64, requires_grad=True)
+        off, feats = 0, []
+        for r, t, gsz in zip(enc.rows(), ts, gs):
+            feats.append(ON.hash_table_encoding(x.double(), t64[off:off + 2 * r].reshape(r, 2), gsz, t,
+                                                torch.tensor(lo, dtype=F64), torch.tensor(hi, dtype=F64), False))
+            off += 2 * r
+        (out,) = torch.autograd.grad((torch.cat(feats, 1) * g).sum(), t64)
+        return out
+
+    return enc, x, g_enc, scatter64(g_enc.double()), scatter64(g_enc.double().abs())
+
+
+def test_scatter_without_bound_keeps_small_entries():
+    """the plain scatter of the exact-fp32 path (no level bound handed in) must not flush small contributions.
+    Gradients spanning 12 decades, checked PER ENTRY against the float64 scatter: every entry within 1e-5 relative + an
+    absolute floor of 2^-40 of the level's largest contribution (the 64-bit fixed point of the reduce pass)."""
+    from learn_nerf import ops
+
+    enc, x, g_enc, g_ref, g_abs = _scatter_case()
+    g_tab = torch.zeros(enc.num_table_floats(), device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x.cuda(), g_enc.t().contiguous().cuda(), g_tab)
+    got = g_tab.cpu().double()
+    floor = g_enc.abs().max().item() * 2.0 ** -40
+    err = (got - g_ref).abs()
+    # 1e-5 of the entry itself, 1e-6 of the sum of the magnitudes that went into it (cancellation), the fixed-point floor
+    bad = err > 1e-5 * g_ref.abs() + 1e-6 * g_abs + floor
+    small = (g_ref.abs() > 0) & (g_ref.abs() < 1e-8)
+    print(f"entries {int((g_ref != 0).sum())}, of them below 1e-8: {int(small.sum())}; worst relative error "
+          f"{(err / g_ref.abs().clamp_min(1e-30))[g_ref.abs() > floor * 1e3].max().item():.2e}")
+    assert int(small.sum()) > 100, "the case must contain small entries"
+    assert not bad.any(), int(bad.sum())
+    # the small entries are really there (not flushed): at least 99 % of them non-zero on the device
+    assert (got[small] != 0).float().mean().item() > 0.99
+
+
+def test_scatter_with_bound_is_quantised_as_documented():
+    """With a per-level bound (what lnrf_ngp_mlp_bwd hands over on the fused bf16 path) the contributions are 26-bit fixed
+    point of that bound: per entry the error is at most (number of contributions) x 2^-26 x bound, small entries may be
+    flushed — the documented quantisation (parity of InstantNGP training on the fused path is unpinned beyond it)."""
+    from learn_nerf import ops
+
+    enc, x, g_enc, g_ref, _ = _scatter_case()
+    g_t = g_enc.t().contiguous().cuda()
+    bound = g_t.abs().reshape(len(enc.grid_sizes), -1).max(dim=1).values.contiguous()
+    g_tab = torch.zeros(enc.num_table_floats(), device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x.cuda(), g_t, g_tab, level_absmax=bound)
+    err = (g_tab.cpu().double() - g_ref).abs().max().item()
+    # <= 8 m contributions in total; per entry far fewer: a generous count of 4096 per entry
+    assert err < 4096 * 2.0 ** -26 * bound.max().item() + 1e-6 * g_ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("with_bound", [False, True])
+def test_scatter_propagates_nan_and_inf(with_bound):
+    """A NaN or Inf in d loss / d enc must reach the table entries its sample touches (as jax's scatter-add would), not be
+    flushed to zero by the fixed-point path; everything else stays finite and correct."""
+    from learn_nerf import ops
+
+    enc, x, g_enc, g_ref, _ = _scatter_case(m=4000, decades=2)
+    g_enc = g_enc.clone()
+    g_enc[17, 0] = float("nan")   # level 0, feature 0 of sample 17
+    g_enc[99, 3] = float("inf")   # level 1, feature 1 of sample 99
+    g_t = g_enc.t().contiguous().cuda()
+    bound = None
+    if with_bound:
+        bound = torch.nan_to_num(g_t, nan=0.0, posinf=0.0, neginf=0.0).abs().reshape(len(enc.grid_sizes), -1).max(dim=1).values.contiguous()
+    g_tab = torch.zeros(enc.num_table_floats(), device="cuda")
+    ops.hashgrid_bwd(enc.desc(), x.cuda(), g_t, g_tab, level_absmax=bound)
+    got = g_tab.cpu()
+    rows = enc.rows()
+    lvl0 = got[:2 * rows[0]].reshape(rows[0], 2)
+    lvl1 = got[2 * rows[0]:2 * (rows[0] + rows[1])].reshape(rows[1], 2)
+    assert torch.isnan(lvl0[:, 0]).sum().item() >= 1 and not torch.isnan(lvl0[:, 1]).any()
+    assert (torch.isinf(lvl1[:, 1]) | torch.isnan(lvl1[:, 1])).sum().item() >= 1
+    rest = got[2 * (rows[0] + rows[1]):]
+    assert torch.isfinite(rest).all()
