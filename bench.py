@@ -259,16 +259,25 @@ def short_leg(workload, n, device, table_log2, steps=50, warmup=10):
         torch.cuda.synchronize()
         per_step.append(1e3 * (time.perf_counter() - t1))
     _prof.enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):  # pass 2: back to back (what the headline workload measures)
         step(Key(warmup + steps + i), batch)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    gaps = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     prof = _prof.summary()
     _prof.enable(False)
     srt = sorted(per_step)
     step_ms = dict(median=round(srt[len(srt) // 2], 3), min=round(srt[0], 3), max=round(srt[-1], 3),
                    max_at=int(per_step.index(srt[-1])), note="synchronised single steps (host clock), before the timed loop")
+    gs = sorted(gaps)
+    step_ms["back_to_back"] = dict(median=round(gs[len(gs) // 2], 3), min=round(gs[0], 3), max=round(gs[-1], 3),
+                                   max_at=int(gaps.index(gs[-1])), first5=[round(g, 3) for g in gaps[:5]],
+                                   last5=[round(g, 3) for g in gaps[-5:]],
+                                   note="HIP-event time between consecutive steps of the timed loop")
     fams = {k: dict(ms=round(v[1], 4), calls_per_step=v[0] / steps) for k, v in prof.items()}
     out = dict(ms_per_step=round(ms, 3), value=round(n * (COARSE + FINE) / (ms * 1e-3), 1), unit="ray-samples/s",
                steps=steps, warmup=warmup, step_ms=step_ms)

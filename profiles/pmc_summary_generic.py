@@ -32,6 +32,14 @@ for name in sorted(set(fetch) | set(write)):
         continue
     out[name] = dict(launches_per_step=round(n / steps, 2), fetch_bytes_per_step=f / steps, write_bytes_per_step=w / steps,
                      hbm_bytes_per_step=(f + w) / steps, hbm_bytes_per_launch=(f + w) / max(n, 1))
+    # a kernel launched k times per step (e.g. coarse pass, then fine pass): mean bytes of the i-th launch of a step
+    k = n // steps
+    if k >= 2 and k * steps == n:
+        fd = [v for _, v in sorted(fetch.get(name, {}).items(), key=lambda kv: int(kv[0]))]
+        wd = [v for _, v in sorted(write.get(name, {}).items(), key=lambda kv: int(kv[0]))]
+        if len(fd) == n and len(wd) == n:
+            out[name]["hbm_bytes_by_launch_in_step"] = [
+                sum(fd[i::k]) / steps * 1024 * 2 + sum(wd[i::k]) / steps * 1024 for i in range(k)]
     total += (f + w) / steps
 out = dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"]))
 out["_total_hbm_bytes_per_step"] = total
