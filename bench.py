@@ -433,7 +433,7 @@ def main():
                 if os.path.exists(pmc) and n == RAYS_PER_GPU:
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                     if traffic is None and dom == "bwd_ls_pipeline":
-                        traffic = json.load(open(pmc)).get("nerf_bwd_ls_kernel", {}).get("hbm_bytes_per_launch")
+                        traffic = json.load(open(pmc)).get("lnrf::nerf_bwd_ls_kernel", {}).get("hbm_bytes_per_launch")
                     if traffic is not None:
                         traffic_source = (f"profiles/{cand}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
                                           "earlier run of this command (gfx950 FETCH x2 correction), NOT measured in "

@@ -410,7 +410,8 @@ int lnrf_nerf_mlp_bwd_ls2(const lnrf_nerf_shape* shape, const void* packed_a, co
  *   lnrf_refnerf_normal_pass    n_raw[m, 3] = -d spatial_out[:, 0] / dx (ref_nerf.py:38-43: the jax.grad inside
  *                               RefNERFBase.__call__); cdump (lnrf_nerf_bwd_scratch_bytes) keeps the chain states
  *   lnrf_refnerf_trunk_bwd      grads += d L / d Dense_0..8 given g_spatial = d L / d spatial_out [m, ld]
- *                               (first-order path; scratch: lnrf_nerf_bwd_scratch_bytes)
+ *                               (first-order path, on the layer-stationary pipeline of lnrf_nerf_mlp_bwd_ls;
+ *                               scratch: lnrf_refnerf_trunk_bwd_scratch_bytes(m))
  *   lnrf_refnerf_normal_bwd     grads += the second-order term: d L / d Dense_0..8 through n_raw, given
  *                               u = d L / d n_raw [m, 3] (jax.grad of a function that calls jax.grad, train.py:89-90
  *                               over ref_nerf.py:42; scratch: lnrf_nerf_save_bytes; the slab region behind the chain
@@ -423,6 +424,7 @@ int lnrf_refnerf_trunk_fwd(const void* packed, const float* x, int64_t m, void* 
                            int64_t ld, lnrf_stream_t stream);
 int lnrf_refnerf_normal_pass(const void* packed, const void* save, const float* x, int64_t m, void* cdump,
                              float* nraw, lnrf_stream_t stream);
+int64_t lnrf_refnerf_trunk_bwd_scratch_bytes(int64_t m);
 int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, const float* g_spatial, int64_t ld, int64_t m,
                            void* scratch, float* grads, lnrf_stream_t stream);
 int lnrf_refnerf_normal_bwd(const void* packed, const void* save, const void* cdump, const float* x,

@@ -513,7 +513,49 @@ static int64_t ls_counter_bytes() { return ((int64_t)kLsMaxPipelines * kLsStages
 
 extern "C" int64_t lnrf_nerf_bwd_ls_scratch_bytes(const lnrf_nerf_shape* s, int64_t m) {
   if (!nerf_shape_fused(s)) return -1;
+  return lnrf::ls_scratch_bytes(m);
+}
+
+int64_t lnrf::ls_scratch_bytes(int64_t m) {
   return ls_dump_bytes(m) + ls_small_slab_bytes() + ls_counter_bytes() + (int64_t)kLsMaxPipelines * kLsStages * kLsSlabBlockBytes;
+}
+int64_t lnrf::ls_small_slab_off(int64_t m) { return ls_dump_bytes(m); }
+
+int lnrf::launch_ls_pipeline(const void* packed, const void* save, void* scratch, int64_t m, float* grads, hipStream_t st) {
+  int total = 0;
+  int rc = ls_pipelines_for_device(&total);
+  if (rc) return rc;
+  if (total > kLsMaxPipelines) total = kLsMaxPipelines;
+  if (total < 1) {
+    set_error("layer-stationary backward: the device has fewer than 8 CUs");
+    return LNRF_ERR_UNSUPPORTED;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_bwd_ls_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLsLds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
+  const int64_t n_tiles = nerf_tiles_for(m);
+  char* sc = (char*)scratch;
+  unsigned* counters = reinterpret_cast<unsigned*>(sc + ls_dump_bytes(m) + ls_small_slab_bytes());
+  float* slabs = reinterpret_cast<float*>(sc + ls_dump_bytes(m) + ls_small_slab_bytes() + ls_counter_bytes());
+  e = hipMemsetAsync(counters, 0, ls_counter_bytes(), st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
+  LsArgs a;
+  a.n_jobs = 1;
+  a.total_pipelines = total;
+  LsJob& j = a.job[0];
+  j.packed = (const char*)packed;
+  j.save = (const char*)save;
+  j.gdump = sc;
+  j.counters = counters;
+  j.slabs = slabs;
+  j.status = counters + (int64_t)kLsMaxPipelines * kLsStages * kLsCounterStride;
+  j.n_tiles = n_tiles;
+  j.pipelines = total;
+  a.job[1] = a.job[0];
+  hipLaunchKernelGGL(nerf_bwd_ls_kernel, dim3((unsigned)(total * kLsStages)), dim3(kLsThreads), kLsLds, st, a);
+  LNRF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nerf_ls_reduce_kernel, dim3(kLsStages * 64), dim3(256), 0, st, (const float*)slabs, total, grads);
+  LNRF_LAUNCH_CHECK();
+  return LNRF_OK;
 }
 
 extern "C" int64_t lnrf_nerf_bwd_ls_status_offset(const lnrf_nerf_shape* s, int64_t m) {

@@ -218,6 +218,14 @@ int launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const
                       float* grads, hipStream_t stream, WgLayout lay = WgLayout{}, float* slabs = nullptr,
                       bool plain_loads = false);
 
+// Layer-stationary backward of the eight 256 x 256 layers Dense_8 .. Dense_1 of ONE model (nerf_bwd_ls.hip): `scratch` holds
+// the gradient dump with dy8 already written (slots grad_dy_slot(8)..), behind it room for ls_scratch_bytes(m); on return
+// the launches that add dW_1..8 and db_1..8 to `grads` and leave dy7..dy0 in the dump are enqueued.  Used by the NeRFModel
+// backward and by RefNERFModel's first-order trunk backward.  ls_dump_bytes / ls_small_slab_off: layout of `scratch`.
+int64_t ls_scratch_bytes(int64_t m);
+int64_t ls_small_slab_off(int64_t m);
+int launch_ls_pipeline(const void* packed, const void* save, void* scratch, int64_t m, float* grads, hipStream_t stream);
+
 // The 13 problems of one NeRFModel, heaviest first; `blocks[i]` workgroups for problem i (capped by `cap`).
 // Block budget per problem in the order: Dense_1..8 (hidden x hidden), z x dy10m, x_emb x dy0, x_emb x dy5,
 // d_emb x dy10m, h10 x dy11.

@@ -324,6 +324,31 @@ __global__ __launch_bounds__(kThreads) void refnerf_trunk_bwd_chain_kernel(
   hidden_back<7 * 128, 1>(ring, a0, a1, mask[0], gd);
 }
 
+// seed of the layer-stationary trunk backward: dy_8 = bf16(d L / d spatial_out) as the 16 fragments of the dump's dy8 slots
+__global__ __launch_bounds__(kThreads) void refnerf_dy8_kernel(const float* __restrict__ g_z, int64_t ldg, int64_t M,
+                                                               int64_t n_tiles, char* __restrict__ gdump) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t m = tile * kTileCols + c;
+  const bool valid = m < M;
+  DumpAddr gd{gdump, n_tiles, tile, c, h, kGradTileSlots};
+  static_for<16>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    float4 lo = make_float4(0, 0, 0, 0), hi = make_float4(0, 0, 0, 0);
+    if (valid) {
+      const float* gr = g_z + m * ldg + 16 * ks + 4 * h;
+      lo = *reinterpret_cast<const float4*>(gr);
+      hi = *reinterpret_cast<const float4*>(gr + 8);
+    }
+    bf16x8 f;
+    f[0] = (__bf16)lo.x; f[1] = (__bf16)lo.y; f[2] = (__bf16)lo.z; f[3] = (__bf16)lo.w;
+    f[4] = (__bf16)hi.x; f[5] = (__bf16)hi.y; f[6] = (__bf16)hi.z; f[7] = (__bf16)hi.w;
+    stream_store(gd.at(grad_dy_slot(8) + ks), frag_to_bits(f));
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // normal backward, tangent chain: ubar_e = (d emb / dx) u, tbar_l = relu'(h_l) * (tbar_{l-1} W_l), l = 0..7
 // (forward weight stream, no bias); dumps in the layout of the forward save buffer (x_emb and h slots)
@@ -1058,13 +1083,35 @@ extern "C" int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, cons
                  "gradient rows must be 16-byte aligned (ld a multiple of 4, >= 256)");
   if (m == 0) return LNRF_OK;
   const int64_t n_tiles = nerf_tiles_for(m);
-  int rc = set_lds(refnerf_trunk_bwd_chain_kernel, kRefLds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(refnerf_trunk_bwd_chain_kernel, tile_grid(n_tiles), dim3(kThreads), kRefLds, as_stream(stream),
-                     (const char*)packed, (const char*)save, g_spatial, ld, m, n_tiles, (char*)scratch);
+  // layer-stationary form (nerf_bwd_ls.hip): seed dy8, the pipeline forms dy7..dy0, dW_1..8 and db_1..8; the two x_emb
+  // problems (Dense_0, rows 256.. of Dense_5) stay on the split-K kernel.  scratch: lnrf_refnerf_trunk_bwd_scratch_bytes.
+  hipLaunchKernelGGL(refnerf_dy8_kernel, tile_grid(n_tiles), dim3(kThreads), 0, as_stream(stream), g_spatial, ld, m, n_tiles,
+                     (char*)scratch);
   LNRF_LAUNCH_CHECK();
-  return trunk_wgrad(save, scratch, n_tiles, 1, grads, as_stream(stream), slabs_behind_dump(scratch, n_tiles));
+  int rc = launch_ls_pipeline(packed, save, scratch, m, grads, as_stream(stream));
+  if (rc) return rc;
+  WgradArgs a;
+  a.n_problems = 0;
+  int first = 0;
+  for (int k = 0; k < 2; ++k) {
+    WgradProblem p;
+    p.shape = 2; p.x_slot0 = kSaveXin; p.y_slot0 = grad_dy_slot(k == 0 ? 0 : 5); p.dense = k == 0 ? 0 : 5;
+    p.row_map = ROW_XEMB; p.row_off = k == 0 ? 0 : 256; p.col_map = COL_256; p.do_bias = k == 0 ? 1 : 0;
+    p.w_off = p.b_off = p.out_dim = p.n_rows = 0;
+    int64_t nb = 256;
+    const int64_t cap = (n_tiles + 5) / 6;
+    if (nb > cap) nb = cap;
+    p.first_block = first;
+    p.n_blocks = (int)nb;
+    first += (int)nb;
+    a.p[a.n_problems++] = p;
+  }
+  float* small_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + ls_small_slab_off(m));
+  return launch_nerf_wgrad(a, first, save, scratch, n_tiles, grads, as_stream(stream),
+                           WgLayout{kSaveTileSlots, kGradTileSlots}, small_slabs);
 }
+
+extern "C" int64_t lnrf_refnerf_trunk_bwd_scratch_bytes(int64_t m) { return m < 0 ? -1 : ls_scratch_bytes(m); }
 
 extern "C" int lnrf_refnerf_normal_bwd(const void* packed, const void* save, const void* cdump, const float* x,
                                        const float* u, int64_t m, void* scratch, float* grads, lnrf_stream_t stream) {

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "lnrf_refnerf_trunk_pack": (c_int32, [_P, _P, _P]),
     "lnrf_refnerf_trunk_fwd": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P]),
     "lnrf_refnerf_normal_pass": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P]),
+    "lnrf_refnerf_trunk_bwd_scratch_bytes": (c_int64, [c_int64]),
     "lnrf_refnerf_trunk_bwd": (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P]),
     "lnrf_refnerf_normal_bwd": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "lnrf_refnerf_dir_save_bytes": (c_int64, [c_int64]),

@@ -257,7 +257,7 @@ class RefNERFModel(RefNERFBase):
                                      g_sp, g_dir_in[:, hd:], g_aux2, g_dir_in)
         shape = L.NerfShape(5, 4, 256, 128, 10, 4)
         with _prof.section(f"{self.tag}_spatial_bwd"):  # first-order: d L / d spatial_out -> Dense_8 .. Dense_0
-            slease = _ws.lease("ref_scratch", lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), dev)
+            slease = _ws.lease("ref_scratch", lib.lnrf_refnerf_trunk_bwd_scratch_bytes(m), dev)
             scratch = slease.buf
             L.check(lib.lnrf_refnerf_trunk_bwd(L.ptr(packed, torch.uint8), L.ptr(save_buf, torch.uint8), L.ptr(g_full),
                                                ld, m, L.ptr(scratch, torch.uint8), L.ptr(grad_flat), L.stream()),
