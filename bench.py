@@ -188,6 +188,31 @@ def build_loop(workload, precision, table_log2, device, backward="ls"):
                      lr=1e-4, coarse_ts=COARSE, fine_ts=FINE, device=device)
 
 
+def leg_traffic(workload, kernel_names, launch_in_step):
+    """HBM bytes per launch of the dominant kernel family of a secondary workload, from the committed rocprofv3 PMC summary
+    (profiles/r03_<workload>_pmc_summary.json; launch_in_step: 0 = coarse pass, 1 = fine pass)."""
+    path = os.path.join(ROOT, "profiles", f"r03_{workload}_pmc_summary.json")
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    total = 0.0
+    for k in kernel_names:
+        v = d.get(k)
+        if not v:
+            continue
+        per = v.get("hbm_bytes_by_launch_in_step")
+        if per and launch_in_step < len(per) and len(per) == 2:
+            total += per[launch_in_step]
+        elif per and len(per) > 2:  # several launches of the kernel per pass: the pass's share of the step
+            half = len(per) // 2
+            total += sum(per[launch_in_step * half:(launch_in_step + 1) * half])
+        else:
+            return None, None
+    src = (f"profiles/r03_{workload}_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of "
+           f"`bench.py --workload {workload}` (gfx950 FETCH x2 correction), kernels {kernel_names}, NOT measured in this run")
+    return (total if total > 0 else None), src
+
+
 def ngp_roofline(fams, m_c, m_f):
     """gather/scatter roofline: L * 8 corners * F * 4 B per evaluation; the scatter-add counts 2x"""
     for name, v in fams.items():
@@ -201,8 +226,11 @@ def ngp_roofline(fams, m_c, m_f):
     if not hg:
         return None
     dom = max(hg, key=lambda k: hg[k]["ms"])
+    names = (["lnrf::hashgrid_bin_kernel", "lnrf::hashgrid_reduce_kernel"] if dom.endswith("hashgrid_bwd")
+             else ["lnrf::hashgrid_fwd_xcd_kernel", "lnrf::hashgrid_fwd_kernel"])
+    traffic, src = leg_traffic("ngp", names, 0 if dom.startswith("coarse") else 1)
     return dict(bound="hbm", kernel=dom, achieved=hg[dom]["GBps"], peak=8000.0, unit="GB/s",
-                frac=round(hg[dom]["GBps"] / 8000.0, 4), traffic=None)
+                frac=round(hg[dom]["GBps"] / 8000.0, 4), traffic=traffic, traffic_source=src)
 
 
 # RefNERFModel, MACs per evaluation (ref_nerf.py:92-107 widths): trunk Dense_0..8 = 60*256 + 4*256^2 + 316*256 + 3*256^2
@@ -229,8 +257,14 @@ def refnerf_roofline(fams, n, ms_step):
                     best = name
     roofline = None
     if best is not None:
+        kn = {"_spatial_fwd": ["lnrf::refnerf_trunk_fwd_kernel"], "_normal_pass": ["lnrf::refnerf_normal_kernel"],
+              "_spatial_bwd": ["lnrf::refnerf_dy8_kernel", "lnrf::nerf_bwd_ls_kernel"],
+              "_normal_bwd": ["lnrf::refnerf_tangent_kernel"]}
+        names = next(v for k, v in kn.items() if best.endswith(k))
+        traffic, src = leg_traffic("refnerf", names, 0 if best.startswith("coarse") else 1)
         roofline = dict(bound="mfma", kernel=best, achieved=fams[best]["tflops"], peak=PEAK_BF16_FLOPS / 1e12,
-                        unit="TFLOP/s", frac=round(fams[best]["tflops"] / (PEAK_BF16_FLOPS / 1e12), 4), traffic=None,
+                        unit="TFLOP/s", frac=round(fams[best]["tflops"] / (PEAK_BF16_FLOPS / 1e12), 4), traffic=traffic,
+                        traffic_source=src,
                         ms_per_launch=fams[best]["ms"],
                         note="dominant fused-trunk kernel family (chain + weight-gradient launches)")
     tf = n * (COARSE + COARSE + FINE) * 2 * REF_STEP_MAC / (ms_step * 1e-3) / 1e12
