@@ -343,6 +343,15 @@ int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packed, const fl
                       int32_t t, int64_t m, float* density, float* rgb, void* save,
                       lnrf_stream_t stream);
 
+/* The same forward for a backward by lnrf_nerf_mlp_bwd_ls / _ls2 (save must not be NULL): that backward takes the ReLU
+ * masks of Dense_0..7 from the saved activations, so their mask slots in `save` are left unwritten (8 KiB per 32
+ * evaluations less to store, ~1/4 fewer epilogue instructions).  A save written by this entry must NOT be handed to
+ * lnrf_nerf_mlp_bwd / _bwd_chain. */
+int lnrf_nerf_mlp_fwd_ls(const lnrf_nerf_shape* shape, const void* packed, const float* x,
+                         const float* d, const float* rays, int64_t ray_stride, const float* ts,
+                         int32_t t, int64_t m, float* density, float* rgb, void* save,
+                         lnrf_stream_t stream);
+
 /* Split-precision ("bf16x3") evaluation of NeRFModel.__call__ (model.py:43-62), the render / evaluation path:
  * the reference computes this in fp32 (model.py:72, render.py:140); here every fp32 operand is carried as
  * a bf16 pair hi + lo and every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation

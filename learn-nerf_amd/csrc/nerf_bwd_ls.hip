@@ -102,7 +102,7 @@ __device__ __forceinline__ void ls_store16(char* base, unsigned voff, u32x4 v) {
   // The s_nop covers the hazard the compiler handles for its own stores and cannot see here: a store of more than 64 bits
   // reads its data registers for a few cycles after issue, and the next instruction may be a VALU write of one of them.
   if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3 sc1\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "i"(IMM) : "memory");
 }
 __device__ __forceinline__ void ls_flag_store(unsigned* word, unsigned value) {
   unsigned zero = 0u;
@@ -368,7 +368,11 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
         const unsigned xw = w == 0 ? xm.x : (w == 1 ? xm.y : (w == 2 ? xm.z : xm.w));
         ov[w] = relu_gate_pair(__builtin_bit_cast(unsigned, pk), xw);
         if constexpr (w == 3) {
+#ifdef LS_PLAIN_DY_STORES
+          ls_store16<f * kFragBytes, false>(ob, sh ? st_voff1 : st_voff0, ov);
+#else
           ls_store16<f * kFragBytes, true>(ob, sh ? st_voff1 : st_voff0, ov);
+#endif
           if constexpr (f < 3) xm = x_mask(std::integral_constant<int, (f < 3 ? f + 1 : 3)>{});
         }
       }

@@ -28,7 +28,9 @@ struct FwdSeq {
 // ---------------------------------------------------------------------------------------------
 constexpr int kFwdStages = kFwdFrags / kStageFrags;  // 75
 
-template <bool SAVE, bool FROM_RAYS>
+// HMASKS: the ReLU-mask slots of the hidden layers are written too (the chain backward reads them; the layer-stationary
+// backward takes the mask from the saved activation itself and needs only the mask of h10, which is always written).
+template <bool SAVE, bool FROM_RAYS, bool HMASKS = true>
 __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
     const char* __restrict__ packed, const float* __restrict__ xin_g, const float* __restrict__ din_g,
     const float* __restrict__ rays, int64_t ray_stride, const float* __restrict__ ts, int T, int64_t M,
@@ -146,9 +148,10 @@ __global__ __launch_bounds__(kThreads) void nerf_fwd_kernel(
           out[2 * o + 1] = acc_to_frag<1, RELU>(acc);
           save_frag(save_slot + 2 * o, out[2 * o]);
           save_frag(save_slot + 2 * o + 1, out[2 * o + 1]);
-          if constexpr (SAVE && RELU) mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
+          if constexpr (SAVE && RELU && HMASKS)
+            mask_bits[o >> 1] |= relu_bits(out[2 * o], out[2 * o + 1]) << (16 * (o & 1));
         });
-    if constexpr (SAVE && RELU) {
+    if constexpr (SAVE && RELU && HMASKS) {
       *reinterpret_cast<uint4*>(save + dump_off(kSaveMask + S, tile, n_tiles, kSaveTileSlots) + lane * 16) =
           make_uint4(mask_bits[0], mask_bits[1], mask_bits[2], mask_bits[3]);
       mask_bits[0] = mask_bits[1] = mask_bits[2] = mask_bits[3] = 0u;
@@ -571,10 +574,9 @@ static int ensure_lds(K kernel, int bytes) {
   return LNRF_OK;
 }
 
-extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packed, const float* x,
-                                 const float* d, const float* rays, int64_t ray_stride, const float* ts,
-                                 int32_t t, int64_t m, float* density, float* rgb, void* save,
-                                 lnrf_stream_t stream) {
+static int nerf_fwd_launch(const lnrf_nerf_shape* shape, const void* packed, const float* x, const float* d,
+                           const float* rays, int64_t ray_stride, const float* ts, int32_t t, int64_t m,
+                           float* density, float* rgb, void* save, bool hidden_masks, lnrf_stream_t stream) {
   if (!shape_supported(shape)) {
     set_error("lnrf_nerf_mlp_fwd: only the default NeRFModel shape {5,4,256,128,10,4} is fused");
     return LNRF_ERR_UNSUPPORTED;
@@ -589,22 +591,37 @@ extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packe
   const dim3 grid((unsigned)((n_tiles + kWaves - 1) / kWaves)), block(kThreads);
   hipStream_t st = as_stream(stream);
   int rc;
-#define LAUNCH_FWD(SAVE, RAYS)                                                                       \
-  do {                                                                                               \
-    rc = ensure_lds(nerf_fwd_kernel<SAVE, RAYS>, kFusedLds);                                         \
-    if (rc) return rc;                                                                               \
-    hipLaunchKernelGGL((nerf_fwd_kernel<SAVE, RAYS>), grid, block, kFusedLds, st, (const char*)packed, \
-                       x, d, rays, ray_stride, ts, (int)t, m, n_tiles, density, rgb, (char*)save);   \
+#define LAUNCH_FWD(SAVE, RAYS, HM)                                                                        \
+  do {                                                                                                    \
+    rc = ensure_lds(nerf_fwd_kernel<SAVE, RAYS, HM>, kFusedLds);                                          \
+    if (rc) return rc;                                                                                    \
+    hipLaunchKernelGGL((nerf_fwd_kernel<SAVE, RAYS, HM>), grid, block, kFusedLds, st, (const char*)packed, \
+                       x, d, rays, ray_stride, ts, (int)t, m, n_tiles, density, rgb, (char*)save);        \
   } while (0)
-  const bool use_save_kernel = save != nullptr;
-  if (use_save_kernel) {
-    if (from_rays) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false);
+  if (save != nullptr && hidden_masks) {
+    if (from_rays) LAUNCH_FWD(true, true, true); else LAUNCH_FWD(true, false, true);
+  } else if (save != nullptr) {
+    if (from_rays) LAUNCH_FWD(true, true, false); else LAUNCH_FWD(true, false, false);
   } else {
-    if (from_rays) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false);
+    if (from_rays) LAUNCH_FWD(false, true, true); else LAUNCH_FWD(false, false, true);
   }
 #undef LAUNCH_FWD
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
+}
+
+extern "C" int lnrf_nerf_mlp_fwd(const lnrf_nerf_shape* shape, const void* packed, const float* x,
+                                 const float* d, const float* rays, int64_t ray_stride, const float* ts,
+                                 int32_t t, int64_t m, float* density, float* rgb, void* save,
+                                 lnrf_stream_t stream) {
+  return nerf_fwd_launch(shape, packed, x, d, rays, ray_stride, ts, t, m, density, rgb, save, true, stream);
+}
+
+extern "C" int lnrf_nerf_mlp_fwd_ls(const lnrf_nerf_shape* shape, const void* packed, const float* x,
+                                    const float* d, const float* rays, int64_t ray_stride, const float* ts,
+                                    int32_t t, int64_t m, float* density, float* rgb, void* save,
+                                    lnrf_stream_t stream) {
+  return nerf_fwd_launch(shape, packed, x, d, rays, ray_stride, ts, t, m, density, rgb, save, false, stream);
 }
 
 extern "C" int64_t lnrf_nerf_packed_split_bytes(const lnrf_nerf_shape* s) {

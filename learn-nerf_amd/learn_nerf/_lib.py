@@ -107,6 +107,8 @@ PROTOTYPES = {
     "lnrf_nerf_pack_weights": (c_int32, [POINTER(NerfShape), _P, _P, _P]),
     "lnrf_nerf_mlp_fwd": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, c_int64, _P, c_int32, c_int64, _P, _P,
                                     _P, _P]),
+    "lnrf_nerf_mlp_fwd_ls": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, c_int64, _P, c_int32, c_int64, _P, _P,
+                                       _P, _P]),
     "lnrf_nerf_packed_split_bytes": (c_int64, [POINTER(NerfShape)]),
     "lnrf_nerf_pack_weights_split": (c_int32, [POINTER(NerfShape), _P, _P, _P]),
     "lnrf_nerf_mlp_fwd_split": (c_int32, [POINTER(NerfShape), _P, _P, _P, _P, c_int64, _P, c_int32, c_int64, _P, _P,

@@ -286,13 +286,17 @@ class NeRFModel(ModelBase):
         if save:  # leased for the life of the backward context (a step-persistent block, see _ws.py)
             save_lease = _ws.lease("nerf_save", L.lib().lnrf_nerf_save_bytes(ctypes.byref(shape), m), dev)
             save_buf = save_lease.buf
+        # the layer-stationary backward takes the hidden layers' ReLU masks from the saved activations: its forward
+        # leaves their mask slots unwritten (lnrf_nerf_mlp_fwd_ls)
+        hidden_masks = not (save and self.backward_kernel == "ls")
+        fwd = L.lib().lnrf_nerf_mlp_fwd if hidden_masks else L.lib().lnrf_nerf_mlp_fwd_ls
         with _prof.section(f"{self.tag}_fwd"):
-            L.check(L.lib().lnrf_nerf_mlp_fwd(
+            L.check(fwd(
                 ctypes.byref(shape), L.ptr(packed, torch.uint8), L.ptr(x), L.ptr(d), L.ptr(rays), rstride,
                 L.ptr(ts), t, m, L.ptr(density), L.ptr(rgb), L.ptr(save_buf, torch.uint8), L.stream()),
                 "nerf_mlp_fwd")
         ctx = (dict(kind="fused", packed=packed, save=save_buf, save_lease=save_lease, density=density, rgb=rgb, m=m,
-                    tag=self.tag) if save else None)
+                    tag=self.tag, hidden_masks=hidden_masks) if save else None)
         return density, rgb, ctx
 
     def forward_points(self, flat, x, d, save: bool):
@@ -328,6 +332,9 @@ class NeRFModel(ModelBase):
                 return
             if self.backward_kernel != "split":
                 raise ValueError(f"unknown backward_kernel {self.backward_kernel!r}")
+            if not ctx.get("hidden_masks", True):
+                raise ValueError("this forward was saved for the layer-stationary backward (no hidden ReLU-mask slots): "
+                                 "set backward_kernel before the forward")
             lease = _ws.lease("nerf_bwd", L.lib().lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), m), grad_flat.device)
             scratch = lease.buf
             with _prof.section(f"{tag}_bwd_chain"):
