@@ -443,8 +443,8 @@ struct WgStage {
   }
 };
 
-// slab epilogue of wgrad_body: floats per (workgroup, wave): up to 8 accumulator tiles of 64 lanes x 16 + 4 bias rows
-constexpr int kSlabMaxTiles = 8, kSlabMaxTO = 4;
+// slab epilogue of wgrad_body: floats per (workgroup, wave): up to 9 accumulator tiles of 64 lanes x 16 + 4 bias rows
+constexpr int kSlabMaxTiles = 9, kSlabMaxTO = 4;
 constexpr int kSlabTileFloats = 64 * 16;
 constexpr int kSlabWaveFloats = kSlabMaxTiles * kSlabTileFloats + kSlabMaxTO * 64;
 constexpr int64_t kSlabBlockBytes = (int64_t)kWaves * kSlabWaveFloats * (int64_t)sizeof(float);
@@ -605,8 +605,9 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
     if (wi == 0 && pb.do_bias) {
       float sacc = bsum[b];
       sacc += __shfl_xor(sacc, 32, 64);
-      if (hh == 0 && out_idx >= 0) atomicAdd(grads + b_off + out_idx, sacc);
+      if (hh == 0 && out_idx >= 0 && b_off >= 0) atomicAdd(grads + b_off + out_idx, sacc);
     }
+    const int row_lim = EPI::row_limit(pb, ot);
     static_for<TI>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       const int it = wi + WI * a;
@@ -616,7 +617,7 @@ __device__ __forceinline__ void wgrad_body(const PB& pb, const char* __restrict_
         const int f = 2 * it + (r >> 4);                   // k-step slot within X
         const int r16 = r & 15;
         const int in_idx = EPI::row(pb, f, r16);  // kernel row of that X feature, -1 = padding
-        if (it < NI && out_idx >= 0 && in_idx >= 0)
+        if (it < NI && out_idx >= 0 && in_idx >= 0 && in_idx < row_lim)
           atomicAdd(grads + w_off + (int64_t)in_idx * out_dim + out_idx,
                     acc[a][b][qq]);
       });
@@ -693,17 +694,18 @@ __device__ __forceinline__ void wgrad_reduce_tile(const PB& pb, int w, int j, co
   int out_idx = -1, out_dim = 1;
   int64_t w_off = 0, b_off = 0;
   EPI::cols(pb, ot, colr, out_idx, out_dim, w_off, b_off);
+  const int row_lim = EPI::row_limit(pb, ot);
   if (bias) {
     float sacc = bsum;
     sacc += __shfl_xor(sacc, 32, 64);
-    if (hh == 0 && out_idx >= 0) grads[b_off + out_idx] += sacc;
+    if (hh == 0 && out_idx >= 0 && b_off >= 0) grads[b_off + out_idx] += sacc;
   }
 #pragma unroll
   for (int qq = 0; qq < 16; ++qq) {
     const int r = (qq & 3) + 8 * (qq >> 2) + 4 * hh;  // row in the 32-feature tile
     const int f = 2 * it + (r >> 4);                   // k-step slot within X
     const int in_idx = EPI::row(pb, f, r & 15);
-    if (out_idx >= 0 && in_idx >= 0) grads[w_off + (int64_t)in_idx * out_dim + out_idx] += acc[qq];
+    if (out_idx >= 0 && in_idx >= 0 && in_idx < row_lim) grads[w_off + (int64_t)in_idx * out_dim + out_idx] += acc[qq];
   }
 }
 

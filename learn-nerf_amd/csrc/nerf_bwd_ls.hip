@@ -512,6 +512,13 @@ static int ls_pipelines_for_device(int* out) {
 }
 constexpr int kLsMaxPipelines = 64;
 static int64_t ls_dump_bytes(int64_t m) { return (int64_t)kGradSlots * nerf_tiles_for(m) * kFragBytes; }
+// workgroups of the three small problems (x_emb x [dy0 | dy5], [z | d_emb] x dy10m, h10 x dy11), in proportion to the bytes
+// they stream per tile (36, 28, 10 KiB)
+static int ls_small_blocks(int i) {
+  static const int total = exp_env_int("LNRF_LS_SMALL_BLOCKS", 256);  // experiment builds only (common.h)
+  const int share[3] = {36, 28, 10};
+  return total * share[i] / 74;
+}
 static int64_t ls_small_slab_bytes() { return 512 * kSlabBlockBytes; }
 static int64_t ls_counter_bytes() { return ((int64_t)kLsMaxPipelines * kLsStages * kLsCounterStride + 64) * (int64_t)sizeof(unsigned); }
 
@@ -660,12 +667,11 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
       first += (int)nb;
       w.p[w.n_problems++] = p;
     };
-    // workgroups in proportion to the bytes a problem streams per tile (26, 20, 20, 12, 10 KiB): 512 = two per CU
-    add(151, 1, kSaveZ, kGradDy10m, 10, ROW_HIDDEN, 0, COL_DY10M, 1);      // Dense_10 rows 0..255 and Dense_9
-    add(116, 2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_256, 1);    // Dense_0
-    add(116, 2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, COL_256, 0);  // Dense_5 rows 256..315
-    add(70, 3, kSaveDin, kGradDy10m, 10, ROW_DEMB, 256, COL_DY10M, 0);     // Dense_10 rows 256..279
-    add(59, 4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);       // Dense_11
+    // workgroups in proportion to the bytes a problem streams per tile (36, 28, 10 KiB): 256 = one per CU (384 = one and a half rounds is 10 % slower, 512 equal within the box-to-box spread).
+    // [z | d_emb] and [dy0 | dy5] are neighbours in the save / dump layouts (nerf_layout.h), so dy10m and x_emb are read once.
+    add(ls_small_blocks(0), 7, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, COL_DY0_DY5, 1);   // Dense_0 and Dense_5 rows 256..315
+    add(ls_small_blocks(1), 6, kSaveZ, kGradDy10m, 10, ROW_Z_DEMB, 0, COL_DY10M, 1);         // Dense_10 (all 280 rows) and Dense_9
+    add(ls_small_blocks(2), 4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);          // Dense_11
     float* small_slabs = reinterpret_cast<float*>((char*)md.scratch + ls_dump_bytes(md.m));
     rc = launch_nerf_wgrad(w, first, md.save, md.scratch, n_tiles, md.grads, st, WgLayout{kSaveTileSlots, kGradTileSlots},
                            small_slabs, false);

@@ -28,8 +28,12 @@ static inline int64_t nerf_tiles_for(int64_t m) {
 //   flag 0  = dy11 (2 slots) + dy10m incl. the density-logit slot (10 slots)   [known after layer T0]
 //   flag t  = output of chain layer T_t, t = 1..9: dy8, dy7, ..., dy0 (16 slots each)
 constexpr int kChainFlags = 10;
-NL_HD constexpr int flag_of_slot(int slot) { return slot < kGradDy ? 0 : 1 + (slot - kGradDy) / 16; }
-NL_HD constexpr int flag_slot0(int f) { return f == 0 ? 0 : kGradDy + 16 * (f - 1); }
+NL_HD constexpr int flag_slot0(int f) { return f == 0 ? 0 : grad_dy_slot(9 - f); }
+NL_HD constexpr int flag_of_slot(int slot) {
+  for (int f = 1; f < kChainFlags; ++f)
+    if (slot >= flag_slot0(f) && slot < flag_slot0(f) + 16) return f;
+  return 0;
+}
 NL_HD constexpr int flag_slots(int f) { return f == 0 ? kGradDy : 16; }
 
 // Sink of the separate-launch path: fragments go to the gradient dump (layout: fused_chain.h dump_off) with non-temporal stores.
@@ -156,8 +160,8 @@ __device__ __forceinline__ void bwd_chain_tile(RING& ring, SINK& sink, const cha
 // ---------------------------------------------------------------------------------------------
 // weight-gradient problems  dW_l[in][out] += sum_m X_l[m][in] * dy_l[m][out]
 // ---------------------------------------------------------------------------------------------
-enum { ROW_HIDDEN = 0, ROW_XEMB = 1, ROW_DEMB = 2 };
-enum { COL_256 = 0, COL_DY10M = 1, COL_DY11 = 2, COL_EXPLICIT = 3 };
+enum { ROW_HIDDEN = 0, ROW_XEMB = 1, ROW_DEMB = 2, ROW_Z_DEMB = 3 };  // ROW_Z_DEMB: 16 slots of z, then 2 of d_emb
+enum { COL_256 = 0, COL_DY10M = 1, COL_DY11 = 2, COL_EXPLICIT = 3, COL_DY0_DY5 = 4 };  // COL_DY0_DY5: tiles 0..7 dy0, 8..15 dy5
 struct WgradProblem {
   int shape;     // operand-shape body, see nerf_wgrad_kernel
   int x_slot0;   // first X slot in the forward save buffer
@@ -185,7 +189,15 @@ struct NerfWgradEpi {
     int dense_w = pb.dense;
     if (pb.col_map == COL_DY10M) {  // tiles 0..3 = Dense_10 outputs, tile 4 column 0 = Dense_9
       if (ot < 4) { out_idx = 32 * ot + colr; out_dim = 128; dense_w = 10; }
-      else if (colr == 0 && pb.row_map == ROW_HIDDEN) { out_idx = 0; out_dim = 1; dense_w = 9; }
+      else if (colr == 0 && pb.row_map != ROW_DEMB) { out_idx = 0; out_dim = 1; dense_w = 9; }
+    } else if (pb.col_map == COL_DY0_DY5) {  // x_emb rows: Dense_0 (with its bias), then rows 256.. of Dense_5 (no bias)
+      out_idx = 32 * (ot & 7) + colr; out_dim = 256;
+      if (ot >= 8) {
+        w_off = dense_w_off(5) + 256 * 256;
+        b_off = -1;
+        return;
+      }
+      dense_w = 0;
     } else if (pb.col_map == COL_DY11) {
       if (colr < 3) { out_idx = colr; out_dim = 3; }
     } else if (pb.col_map == COL_EXPLICIT) {
@@ -206,9 +218,19 @@ struct NerfWgradEpi {
     if (pb.row_map == ROW_HIDDEN) {
       in_idx = 16 * f + r16;
       if (pb.col_map == COL_EXPLICIT && in_idx >= pb.n_rows) in_idx = -1;
+    } else if (pb.row_map == ROW_Z_DEMB) {
+      if (f < 16) in_idx = 16 * f + r16;
+      else {
+        in_idx = demb_feat(f - 16, sh, sj);
+        if (in_idx >= 0) in_idx += 256;
+      }
     } else if (pb.row_map == ROW_XEMB) in_idx = xemb_feat(f, sh, sj);
     else in_idx = demb_feat(f, sh, sj);
     return in_idx >= 0 ? in_idx + pb.row_off : -1;
+  }
+  // rows of the kernel behind column tile `ot` (rows at or above it belong to no parameter): Dense_9 takes z only
+  static __device__ __forceinline__ int row_limit(const WgradProblem& pb, int ot) {
+    return pb.col_map == COL_DY10M && ot >= 4 ? 256 : 0x7FFFFFFF;
   }
 };
 

@@ -322,10 +322,11 @@ NL_HD constexpr int dump_lane_off(int slot, int c, int hh) {
 }
 // forward save slots
 constexpr int kSaveXin = 0;    // 4 slots
-constexpr int kSaveDin = 4;    // 2 slots
-constexpr int kSaveH = 6;      // h0..h7 (relu outputs of Dense_0..7): 16 slots each
-constexpr int kSaveZ = 6 + 8 * 16;      // z = Dense_8 output (linear): 16 slots
-constexpr int kSaveH10 = kSaveZ + 16;   // relu(Dense_10): 8 slots
+constexpr int kSaveH = 4;      // h0..h7 (relu outputs of Dense_0..7): 16 slots each
+constexpr int kSaveZ = 4 + 8 * 16;      // z = Dense_8 output (linear): 16 slots
+constexpr int kSaveDin = kSaveZ + 16;   // d_emb, 2 slots, right behind z: [z | d_emb] is the input of Dense_10 and ONE
+                                        // operand of its weight-gradient problem (dy10m is then read once, not twice)
+constexpr int kSaveH10 = kSaveDin + 2;  // relu(Dense_10): 8 slots
 constexpr int kSaveMask = kSaveH10 + 8;   // ReLU masks, one 1 KiB slot per layer: h0..h7, h10 (9 slots);
                                           // lane l keeps a uint4 at l*16: bit 16*o + q of the 128 = acc reg q
                                           // of out-tile o was > 0
@@ -333,7 +334,7 @@ constexpr int kSaveSlots = kSaveMask + 9;  // 167
 // backward dump slots (pre-activation gradients)
 constexpr int kGradDy11 = 0;            // 2 slots (second is zero padding)
 constexpr int kGradDy10m = 2;           // 10 slots: 8 for Dense_10 outputs, slot 8 = logit, slot 9 zero
-constexpr int kGradDy = 12;             // dy8, dy7, ..., dy0: 16 slots each, index (8 - l)
+constexpr int kGradDy = 12;             // dy8, dy7, dy6, dy4, dy3, dy2, dy1, dy0, dy5: 16 slots each (grad_dy_slot)
 constexpr int kGradSlots = kGradDy + 9 * 16;  // 156
 // NeRFModel dump layout: tile-major unless built with -DLNRF_DUMP_SLOT_MAJOR (A/B; see fused_chain.h dump_off)
 #ifdef LNRF_DUMP_SLOT_MAJOR
@@ -342,7 +343,9 @@ constexpr int kSaveTileSlots = 0, kGradTileSlots = 0, kDirSaveTileSlots = 0, kDi
 constexpr int kSaveTileSlots = kSaveSlots, kGradTileSlots = kGradSlots;
 constexpr int kDirSaveTileSlots = kDirSaveSlots, kDirGradTileSlots = kDirGradSlots;  // Ref-NeRF directional block
 #endif
-NL_HD constexpr int grad_dy_slot(int l) { return kGradDy + (8 - l) * 16; }
+// dy5 sits behind dy0: x_emb^T [dy0 | dy5] (Dense_0 and rows 256.. of Dense_5) is ONE weight-gradient problem
+NL_HD constexpr int grad_dy_pos(int l) { return l == 5 ? 8 : (l > 5 ? 8 - l : 7 - l); }
+NL_HD constexpr int grad_dy_slot(int l) { return kGradDy + grad_dy_pos(l) * 16; }
 
 }  // namespace nl
 }  // namespace lnrf

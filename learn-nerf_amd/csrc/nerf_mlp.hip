@@ -428,16 +428,18 @@ __global__ __launch_bounds__(kThreads) void nerf_wgrad_kernel(WgradArgs args, co
     case 2: wgrad_body<4, 16, 2, 4, 3, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
     case 3: wgrad_body<2, 10, 1, 8, 5, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
     case 5: wgrad_body<18, 8, 4, 2, 2, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // Ref-NeRF Dense_9
+    case 6: wgrad_body<18, 10, 4, 2, 2, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;  // [z | d_emb] x dy10m
+    case 7: wgrad_body<4, 32, 2, 4, 2, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;   // x_emb x [dy0 | dy5]
     default: wgrad_body<8, 2, 4, 2, 6, NerfWgradEpi, PLAIN, (kSaveTileSlots > 0)>(pb, save, gdump, n_tiles, grads, lay, slabs); break;
   }
 }
 
-// Folds the slabs of a nerf_wgrad_kernel launch (slab epilogue): blockIdx.x = problem * 64 + wave * 8 + tile.
+// Folds the slabs of a nerf_wgrad_kernel launch (slab epilogue): blockIdx.x = (problem * 8 + wave) * kSlabMaxTiles + tile.
 __global__ __launch_bounds__(64 * kSlabReduceWaves) void nerf_wgrad_reduce_kernel(WgradArgs args,
                                                                                  const float* __restrict__ slabs,
                                                                                  float* __restrict__ grads) {
   __shared__ float lds[(kSlabReduceWaves - 1) * 17 * 64];
-  const int prob = blockIdx.x >> 6, w = (blockIdx.x >> 3) & 7, j = blockIdx.x & 7;
+  const int prob = blockIdx.x / (kWaves * kSlabMaxTiles), w = blockIdx.x / kSlabMaxTiles % kWaves, j = blockIdx.x % kSlabMaxTiles;
   const WgradProblem pb = args.p[prob];
   switch (pb.shape) {  // the shapes of nerf_wgrad_kernel
     case 0: wgrad_reduce_tile<16, 16, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
@@ -445,6 +447,8 @@ __global__ __launch_bounds__(64 * kSlabReduceWaves) void nerf_wgrad_reduce_kerne
     case 2: wgrad_reduce_tile<4, 16, 2, 4, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
     case 3: wgrad_reduce_tile<2, 10, 1, 8, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
     case 5: wgrad_reduce_tile<18, 8, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    case 6: wgrad_reduce_tile<18, 10, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
+    case 7: wgrad_reduce_tile<4, 32, 2, 4, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
     default: wgrad_reduce_tile<8, 2, 4, 2, NerfWgradEpi>(pb, w, j, slabs, grads, lds); break;
   }
 }
@@ -452,35 +456,36 @@ __global__ __launch_bounds__(64 * kSlabReduceWaves) void nerf_wgrad_reduce_kerne
 // ---------------------------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------------------------
+// One thread per lane slot of a fragment (8 bf16 = one 16-byte store) or per bias float.
 __global__ void nerf_pack_kernel(const float* __restrict__ params, char* __restrict__ packed) {
-  const int64_t total_f = (int64_t)kFwdFrags * 512;
-  const int64_t total_b = (int64_t)kBwdFrags * 512;
-  const int64_t total = total_f + total_b + kBiasFloats;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    if (e < total_f + total_b) {
-      const bool fwd = e < total_f;
-      const int64_t ee = fwd ? e : e - total_f;
-      const int g = (int)(ee >> 9), lane = (int)((ee >> 3) & 63), j = (int)(ee & 7);
-      int idx = -1;
+  constexpr int64_t units_f = (int64_t)kFwdFrags * 64, units_b = (int64_t)kBwdFrags * 64;
+  constexpr int64_t total = units_f + units_b + kBiasFloats;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
+    if (u < units_f + units_b) {
+      const bool fwd = u < units_f;
+      const int64_t uu = fwd ? u : u - units_f;
+      const int g = (int)(uu >> 6), lane = (int)(uu & 63);
+      int layer = 0, loc, nk, n_used;
       if (fwd) {
-        int s = 0;
         for (int i = 1; i < kFwdLayers; ++i)
-          if (g >= fwd_base(i)) s = i;
-        const int loc = g - fwd_base(s);
-        if (loc < fwd_nk(s) * fwd_no(s)) idx = fwd_weight_index(s, loc / fwd_nk(s), loc % fwd_nk(s), lane, j);
+          if (g >= fwd_base(i)) layer = i;
+        loc = g - fwd_base(layer); nk = fwd_nk(layer); n_used = nk * fwd_no(layer);
       } else {
-        int t = 0;
         for (int i = 1; i < kBwdLayers; ++i)
-          if (g >= bwd_base(i)) t = i;
-        const int loc = g - bwd_base(t);
-        if (loc < bwd_nk(t) * bwd_no(t)) idx = bwd_weight_index(t, loc / bwd_nk(t), loc % bwd_nk(t), lane, j);
+          if (g >= bwd_base(i)) layer = i;
+        loc = g - bwd_base(layer); nk = bwd_nk(layer); n_used = nk * bwd_no(layer);
       }
-      const float v = idx >= 0 ? params[idx] : 0.0f;
-      __bf16* dst = reinterpret_cast<__bf16*>(packed + (fwd ? kPackFwdOff : kPackBwdOff));
-      dst[ee] = (__bf16)v;
+      bf16x8 out;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int idx = -1;
+        if (loc < n_used) idx = fwd ? fwd_weight_index(layer, loc / nk, loc % nk, lane, j)
+                                    : bwd_weight_index(layer, loc / nk, loc % nk, lane, j);
+        out[j] = (__bf16)(idx >= 0 ? params[idx] : 0.0f);
+      }
+      *reinterpret_cast<bf16x8*>(packed + (fwd ? kPackFwdOff : kPackBwdOff) + uu * 16) = out;
     } else {
-      const int i = (int)(e - total_f - total_b);
+      const int i = (int)(u - units_f - units_b);
       int s = 0;
       for (int k = 1; k < kFwdLayers; ++k)
         if (i >= fwd_bias_base(k)) s = k;
@@ -561,7 +566,7 @@ extern "C" int lnrf_nerf_pack_weights(const lnrf_nerf_shape* shape, const float*
     return LNRF_ERR_UNSUPPORTED;
   }
   LNRF_CHECK_ARG(params && packed, "null pointer");
-  hipLaunchKernelGGL(nerf_pack_kernel, dim3(1024), dim3(256), 0, as_stream(stream), params, (char*)packed);
+  hipLaunchKernelGGL(nerf_pack_kernel, dim3(640), dim3(256), 0, as_stream(stream), params, (char*)packed);
   LNRF_LAUNCH_CHECK();
   return LNRF_OK;
 }
@@ -704,7 +709,7 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
 
 int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
                             float* grads, hipStream_t stream, WgLayout lay, float* slabs, bool plain) {
-  const int lds = 2 * 2 * 32 * kFragBytes;  // largest body: 2 buffers x 2 steps x (16 + 16) fragments
+  const int lds = 2 * 2 * 36 * kFragBytes;  // largest body: 2 buffers x 2 steps x (4 + 32) fragments
   hipError_t e = hipFuncSetAttribute(plain ? reinterpret_cast<const void*>(nerf_wgrad_kernel<true>)
                                            : reinterpret_cast<const void*>(nerf_wgrad_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -721,7 +726,7 @@ int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf,
                        (const char*)xbuf, (const char*)ybuf, n_tiles, grads, lay, slabs);
   LNRF_LAUNCH_CHECK();
   if (slabs != nullptr) {  // room for `blocks` slabs of kSlabBlockBytes is the caller's business
-    hipLaunchKernelGGL(nerf_wgrad_reduce_kernel, dim3((unsigned)(args.n_problems * 64)), dim3(64 * kSlabReduceWaves), 0, stream, args,
+    hipLaunchKernelGGL(nerf_wgrad_reduce_kernel, dim3((unsigned)(args.n_problems * kWaves * kSlabMaxTiles)), dim3(64 * kSlabReduceWaves), 0, stream, args,
                        (const float*)slabs, grads);
     LNRF_LAUNCH_CHECK();
   }

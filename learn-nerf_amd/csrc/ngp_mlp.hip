@@ -100,6 +100,7 @@ struct NgpWgradEpi {
     const int nv = f == 0 ? pb.rv0 : (f == 1 ? pb.rv1 : (f == 2 ? pb.rv2 : pb.rv3));
     return r16 < nv ? base + r16 : -1;
   }
+  static __device__ __forceinline__ int row_limit(const NgpWgradProblem&, int) { return 0x7FFFFFFF; }
 };
 // k-parts of the fused mode per weight-gradient problem (host table order: Dense_3, Dense_2, Dense_1, Dense_4,
 // Dense_0): a layer with NT < 4 dW tiles is dealt to its four waves as NT tiles x 4 / NT parts of the group's 256

@@ -45,8 +45,8 @@ def test_size_queries_without_gpu():
     assert lib.lnrf_nerf_param_count(ctypes.byref(shape)) == 593_924
     assert lib.lnrf_nerf_packed_bytes(ctypes.byref(shape)) == (1200 + 1120) * 1024 + 10240
     assert lib.lnrf_nerf_save_bytes(ctypes.byref(shape), 4096 * 192) == 167 * 24576 * 1024
-    # gradient dump (tiles padded to 8-wave workgroups) + 512 partial-sum slabs of 8 waves x (8 tiles x 4 KiB + 4 bias rows)
-    assert lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), 33) == 156 * 8 * 1024 + 512 * 8 * (8 * 4096 + 4 * 256)
+    # gradient dump (tiles padded to 8-wave workgroups) + 512 partial-sum slabs of 8 waves x (9 tiles x 4 KiB + 4 bias rows)
+    assert lib.lnrf_nerf_bwd_scratch_bytes(ctypes.byref(shape), 33) == 156 * 8 * 1024 + 512 * 8 * (9 * 4096 + 4 * 256)
     other = _lib.NerfShape(5, 4, 128, 128, 10, 4)
     assert lib.lnrf_nerf_param_count(ctypes.byref(other)) > 0
     assert lib.lnrf_nerf_packed_bytes(ctypes.byref(other)) == -1  # fused path: default shape only
