@@ -418,10 +418,9 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
 // Folds the slabs of one model: blockIdx.x = stage * 64 + wave * 16 + tile; the four waves of the workgroup sum the
 // pipelines q, q + 4, ... in order, meet in LDS and wave 0 adds the total to the gradient vector (fixed order, one owner
 // per parameter: bit-reproducible).
-__global__ __launch_bounds__(256) void nerf_ls_reduce_kernel(const float* __restrict__ slabs, int pipelines,
-                                                             float* __restrict__ grads) {
-  __shared__ float lds[3 * 17 * 64];
-  const int stage = blockIdx.x >> 6, w = (blockIdx.x >> 4) & 3, j = blockIdx.x & 15;
+__device__ __forceinline__ void ls_fold_block(int bid, const float* __restrict__ slabs, int pipelines,
+                                              float* __restrict__ grads, float* lds) {
+  const int stage = bid >> 6, w = (bid >> 4) & 3, j = bid & 15;
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int l = 8 - stage, a = j >> 3, pos = j & 7;
   const int b = (pos + 2 * w) & 7;       // out tile held at position `pos` of wave w (rotated walk of the pipeline kernel)
@@ -464,6 +463,40 @@ __global__ __launch_bounds__(256) void nerf_ls_reduce_kernel(const float* __rest
   for (int qq = 0; qq < 16; ++qq) {
     const int r = (qq & 3) + 8 * (qq >> 2) + 4 * hh;  // row of the 32-feature in-tile
     grads[dense_w_off(l) + (int64_t)(32 * it + r) * 256 + out] += acc[qq];
+  }
+}
+__global__ __launch_bounds__(256) void nerf_ls_reduce_kernel(const float* __restrict__ slabs, int pipelines,
+                                                             float* __restrict__ grads) {
+  __shared__ float lds[3 * 17 * 64];
+  ls_fold_block(blockIdx.x, slabs, pipelines, grads, lds);
+}
+
+// Every fold of a layer-stationary backward in ONE launch: blockIdx.y = model; blockIdx.x first walks the slabs of the
+// model's small problems (nerf_wgrad_reduce_kernel's work: (problem, wave, tile)), then the pipeline slabs
+// (nerf_ls_reduce_kernel's work).  The two parts own disjoint parameters (Dense_5: rows 256.. here, rows 0..255 there).
+struct LsFoldArgs {
+  WgradArgs w[2];
+  const float* small_slabs[2];
+  const float* ls_slabs[2];
+  float* grads[2];
+  int pipelines[2];
+};
+static_assert(kSlabReduceWaves == 4, "fold workgroups are 4 waves");
+__global__ __launch_bounds__(256) void nerf_ls_fold_kernel(LsFoldArgs a) {
+  __shared__ float lds[3 * 17 * 64];
+  const int k = blockIdx.y;
+  const int n_small = a.w[k].n_problems * kWaves * kSlabMaxTiles;
+  const int bid = blockIdx.x;
+  if (bid < n_small) {
+    const int prob = bid / (kWaves * kSlabMaxTiles), w = bid / kSlabMaxTiles % kWaves, j = bid % kSlabMaxTiles;
+    const WgradProblem pb = a.w[k].p[prob];
+    switch (pb.shape) {  // the shapes ls_backward() launches
+      case 7: wgrad_reduce_tile<4, 32, 2, 4, NerfWgradEpi>(pb, w, j, a.small_slabs[k], a.grads[k], lds); break;
+      case 6: wgrad_reduce_tile<18, 10, 4, 2, NerfWgradEpi>(pb, w, j, a.small_slabs[k], a.grads[k], lds); break;
+      default: wgrad_reduce_tile<8, 2, 4, 2, NerfWgradEpi>(pb, w, j, a.small_slabs[k], a.grads[k], lds); break;
+    }
+  } else if (bid - n_small < kLsStages * 64) {
+    ls_fold_block(bid - n_small, a.ls_slabs[k], a.pipelines[k], a.grads[k], lds);
   }
 }
 
@@ -646,6 +679,7 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
     hipLaunchKernelGGL(nerf_bwd_ls_kernel, dim3((unsigned)(total * kLsStages)), dim3(kLsThreads), kLsLds, st, a);
     LNRF_LAUNCH_CHECK();
   }
+  LsFoldArgs fold;
   for (int k = 0; k < n_models && (phases & 4); ++k) {
     const LsModel& md = mdl[k];
     const int64_t n_tiles = nerf_tiles_for(md.m);
@@ -674,10 +708,21 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
     add(ls_small_blocks(2), 4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);          // Dense_11
     float* small_slabs = reinterpret_cast<float*>((char*)md.scratch + ls_dump_bytes(md.m));
     rc = launch_nerf_wgrad(w, first, md.save, md.scratch, n_tiles, md.grads, st, WgLayout{kSaveTileSlots, kGradTileSlots},
-                           small_slabs, false);
+                           small_slabs, false, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(nerf_ls_reduce_kernel, dim3(kLsStages * 64), dim3(256), 0, st, (const float*)a.job[k].slabs,
-                       pipes[k], md.grads);
+    fold.w[k] = w;
+    fold.small_slabs[k] = small_slabs;
+    fold.ls_slabs[k] = a.job[k].slabs;
+    fold.grads[k] = md.grads;
+    fold.pipelines[k] = pipes[k];
+  }
+  if (phases & 4) {  // one fold launch for everything both models left in slabs
+    if (n_models == 1) {
+      fold.w[1] = fold.w[0]; fold.small_slabs[1] = fold.small_slabs[0]; fold.ls_slabs[1] = fold.ls_slabs[0];
+      fold.grads[1] = fold.grads[0]; fold.pipelines[1] = fold.pipelines[0];
+    }
+    const int gx = fold.w[0].n_problems * kWaves * kSlabMaxTiles + kLsStages * 64;  // both models have the same problems
+    hipLaunchKernelGGL(nerf_ls_fold_kernel, dim3((unsigned)gx, (unsigned)n_models), dim3(256), 0, st, fold);
     LNRF_LAUNCH_CHECK();
   }
   return LNRF_OK;

@@ -238,7 +238,7 @@ struct NerfWgradEpi {
 // dumps of n_tiles tiles in the layout `lay` names: slot-major by default, see fused_chain.h dump_off)
 int launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
                       float* grads, hipStream_t stream, WgLayout lay = WgLayout{}, float* slabs = nullptr,
-                      bool plain_loads = false);
+                      bool plain_loads = false, bool fold = true);  // fold == false: the caller folds the slabs itself
 
 // Layer-stationary backward of the eight 256 x 256 layers Dense_8 .. Dense_1 of ONE model (nerf_bwd_ls.hip): `scratch` holds
 // the gradient dump with dy8 already written (slots grad_dy_slot(8)..), behind it room for ls_scratch_bytes(m); on return

@@ -708,7 +708,7 @@ extern "C" int lnrf_nerf_mlp_bwd(const lnrf_nerf_shape* shape, const void* packe
 }
 
 int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf, const void* ybuf, int64_t n_tiles,
-                            float* grads, hipStream_t stream, WgLayout lay, float* slabs, bool plain) {
+                            float* grads, hipStream_t stream, WgLayout lay, float* slabs, bool plain, bool fold) {
   const int lds = 2 * 2 * 36 * kFragBytes;  // largest body: 2 buffers x 2 steps x (4 + 32) fragments
   hipError_t e = hipFuncSetAttribute(plain ? reinterpret_cast<const void*>(nerf_wgrad_kernel<true>)
                                            : reinterpret_cast<const void*>(nerf_wgrad_kernel<false>),
@@ -725,7 +725,7 @@ int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf,
     hipLaunchKernelGGL(nerf_wgrad_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args,
                        (const char*)xbuf, (const char*)ybuf, n_tiles, grads, lay, slabs);
   LNRF_LAUNCH_CHECK();
-  if (slabs != nullptr) {  // room for `blocks` slabs of kSlabBlockBytes is the caller's business
+  if (slabs != nullptr && fold) {  // room for `blocks` slabs of kSlabBlockBytes is the caller's business
     hipLaunchKernelGGL(nerf_wgrad_reduce_kernel, dim3((unsigned)(args.n_problems * kWaves * kSlabMaxTiles)), dim3(64 * kSlabReduceWaves), 0, stream, args,
                        (const float*)slabs, grads);
     LNRF_LAUNCH_CHECK();
