@@ -418,6 +418,7 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
 // Folds the slabs of one model: blockIdx.x = stage * 64 + wave * 16 + tile; the four waves of the workgroup sum the
 // pipelines q, q + 4, ... in order, meet in LDS and wave 0 adds the total to the gradient vector (fixed order, one owner
 // per parameter: bit-reproducible).
+template <int NW>  // waves of the folding workgroup; lds: (NW - 1) * 17 * 64 floats
 __device__ __forceinline__ void ls_fold_block(int bid, const float* __restrict__ slabs, int pipelines,
                                               float* __restrict__ grads, float* lds) {
   const int stage = bid >> 6, w = (bid >> 4) & 3, j = bid & 15;
@@ -429,7 +430,7 @@ __device__ __forceinline__ void ls_fold_block(int bid, const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float bs = 0.0f;
-  for (int p = q; p < pipelines; p += 4) {
+  for (int p = q; p < pipelines; p += NW) {
     const float* base = slabs + (((int64_t)p * kLsStages + stage) * kLsWaves + w) * kLsSlabWaveFloats;
     const float4* tp = reinterpret_cast<const float4*>(base + j * kSlabTileFloats) + lane;
 #pragma unroll
@@ -447,7 +448,7 @@ __device__ __forceinline__ void ls_fold_block(int bid, const float* __restrict__
   __syncthreads();
   if (q > 0) return;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < NW - 1; ++p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += lds[(p * 17 + r) * 64 + lane];
     bs += lds[(p * 17 + 16) * 64 + lane];
@@ -468,7 +469,7 @@ __device__ __forceinline__ void ls_fold_block(int bid, const float* __restrict__
 __global__ __launch_bounds__(256) void nerf_ls_reduce_kernel(const float* __restrict__ slabs, int pipelines,
                                                              float* __restrict__ grads) {
   __shared__ float lds[3 * 17 * 64];
-  ls_fold_block(blockIdx.x, slabs, pipelines, grads, lds);
+  ls_fold_block<4>(blockIdx.x, slabs, pipelines, grads, lds);
 }
 
 // Every fold of a layer-stationary backward in ONE launch: blockIdx.y = model; blockIdx.x first walks the slabs of the
@@ -481,9 +482,8 @@ struct LsFoldArgs {
   float* grads[2];
   int pipelines[2];
 };
-static_assert(kSlabReduceWaves == 4, "fold workgroups are 4 waves");
-__global__ __launch_bounds__(256) void nerf_ls_fold_kernel(LsFoldArgs a) {
-  __shared__ float lds[3 * 17 * 64];
+__global__ __launch_bounds__(64 * kSlabReduceWaves) void nerf_ls_fold_kernel(LsFoldArgs a) {
+  __shared__ float lds[(kSlabReduceWaves - 1) * 17 * 64];
   const int k = blockIdx.y;
   const int n_small = a.w[k].n_problems * kWaves * kSlabMaxTiles;
   const int bid = blockIdx.x;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void nerf_ls_fold_kernel(LsFoldArgs a) {
       default: wgrad_reduce_tile<8, 2, 4, 2, NerfWgradEpi>(pb, w, j, a.small_slabs[k], a.grads[k], lds); break;
     }
   } else if (bid - n_small < kLsStages * 64) {
-    ls_fold_block(bid - n_small, a.ls_slabs[k], a.pipelines[k], a.grads[k], lds);
+    ls_fold_block<kSlabReduceWaves>(bid - n_small, a.ls_slabs[k], a.pipelines[k], a.grads[k], lds);
   }
 }
 
@@ -722,7 +722,7 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
       fold.grads[1] = fold.grads[0]; fold.pipelines[1] = fold.pipelines[0];
     }
     const int gx = fold.w[0].n_problems * kWaves * kSlabMaxTiles + kLsStages * 64;  // both models have the same problems
-    hipLaunchKernelGGL(nerf_ls_fold_kernel, dim3((unsigned)gx, (unsigned)n_models), dim3(256), 0, st, fold);
+    hipLaunchKernelGGL(nerf_ls_fold_kernel, dim3((unsigned)gx, (unsigned)n_models), dim3(64 * kSlabReduceWaves), 0, st, fold);
     LNRF_LAUNCH_CHECK();
   }
   return LNRF_OK;
