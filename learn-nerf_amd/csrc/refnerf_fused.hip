@@ -1045,17 +1045,19 @@ extern "C" int lnrf_refnerf_normal_pass(const void* packed, const void* save, co
   return LNRF_OK;
 }
 
-// the ten weight-gradient problems of the trunk: Dense_1..8 (hidden x hidden), Dense_0 and the x_emb rows of Dense_5
+// the nine weight-gradient problems of the trunk: Dense_1..8 (hidden x hidden) and x_emb x [dy0 | dy5] (Dense_0 and the
+// x_emb rows of Dense_5: the two dumps are neighbours, nerf_layout.h); 256 workgroups = one per CU (two rounds of 512 cost
+// twice the partial-sum traffic for the same streaming rate)
 // `slabs`: room for 512 workgroups' partial sums (kSlabBlockBytes each) — the deterministic epilogue of fused_chain.h
 static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int do_bias, float* grads, hipStream_t st,
                        float* slabs) {
   WgradArgs a;
   a.n_problems = 0;
   int first = 0;
-  auto add = [&](int shape, int xs, int ys, int dense, int row_map, int row_off, int bias, int blocks) {
+  auto add = [&](int shape, int xs, int ys, int dense, int row_map, int row_off, int bias, int blocks, int col_map) {
     WgradProblem p;
     p.shape = shape; p.x_slot0 = xs; p.y_slot0 = ys; p.dense = dense; p.row_map = row_map; p.row_off = row_off;
-    p.col_map = COL_256; p.do_bias = bias;
+    p.col_map = col_map; p.do_bias = bias;
     p.w_off = p.b_off = p.out_dim = p.n_rows = 0;
     int64_t nb = blocks;
     const int64_t cap = (n_tiles + 5) / 6;
@@ -1065,9 +1067,8 @@ static int trunk_wgrad(const void* xbuf, const void* ybuf, int64_t n_tiles, int 
     first += (int)nb;
     a.p[a.n_problems++] = p;
   };
-  for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, do_bias, 56);
-  add(2, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, do_bias, 32);
-  add(2, kSaveXin, grad_dy_slot(5), 5, ROW_XEMB, 256, 0, 32);
+  for (int l = 1; l <= 8; ++l) add(0, kSaveH + (l - 1) * 16, grad_dy_slot(l), l, ROW_HIDDEN, 0, do_bias, 28, COL_256);
+  add(7, kSaveXin, grad_dy_slot(0), 0, ROW_XEMB, 0, do_bias, 32, COL_DY0_DY5);
   return launch_nerf_wgrad(a, first, xbuf, ybuf, n_tiles, grads, st, WgLayout{kSaveTileSlots, kGradTileSlots},
                            first <= 512 ? slabs : nullptr);
 }
@@ -1093,10 +1094,10 @@ extern "C" int lnrf_refnerf_trunk_bwd(const void* packed, const void* save, cons
   WgradArgs a;
   a.n_problems = 0;
   int first = 0;
-  for (int k = 0; k < 2; ++k) {
+  {  // x_emb x [dy0 | dy5]: Dense_0 (with its bias) and rows 256.. of Dense_5
     WgradProblem p;
-    p.shape = 2; p.x_slot0 = kSaveXin; p.y_slot0 = grad_dy_slot(k == 0 ? 0 : 5); p.dense = k == 0 ? 0 : 5;
-    p.row_map = ROW_XEMB; p.row_off = k == 0 ? 0 : 256; p.col_map = COL_256; p.do_bias = k == 0 ? 1 : 0;
+    p.shape = 7; p.x_slot0 = kSaveXin; p.y_slot0 = grad_dy_slot(0); p.dense = 0;
+    p.row_map = ROW_XEMB; p.row_off = 0; p.col_map = COL_DY0_DY5; p.do_bias = 1;
     p.w_off = p.b_off = p.out_dim = p.n_rows = 0;
     int64_t nb = 256;
     const int64_t cap = (n_tiles + 5) / 6;
@@ -1177,8 +1178,8 @@ extern "C" int lnrf_refnerf_dir_bwd(const void* packed, const void* dsave, const
     first += (int)nb;
     a.p[a.n_problems++] = p;
   };
-  add(5, kDirSaveXin, kDirGradDy9, kDirHidden, kDirIn, kDirW9, kDirB9, 400);
-  add(4, kDirSaveH, kDirGradDy10, 3, kDirHidden, kDirW10, kDirB10, 112);
+  add(5, kDirSaveXin, kDirGradDy9, kDirHidden, kDirIn, kDirW9, kDirB9, 200);  // 256 workgroups = one per CU
+  add(4, kDirSaveH, kDirGradDy10, 3, kDirHidden, kDirW10, kDirB10, 56);
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (int64_t)kDirGradSlots * n_tiles * kFragBytes);
   return launch_nerf_wgrad(a, first, dsave, scratch, n_tiles, grads, as_stream(stream),
                            WgLayout{kDirSaveTileSlots, kDirGradTileSlots}, first <= 512 ? slabs : nullptr);
