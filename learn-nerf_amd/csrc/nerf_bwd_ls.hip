@@ -707,7 +707,9 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
     add(ls_small_blocks(1), 6, kSaveZ, kGradDy10m, 10, ROW_Z_DEMB, 0, COL_DY10M, 1);         // Dense_10 (all 280 rows) and Dense_9
     add(ls_small_blocks(2), 4, kSaveH10, kGradDy11, 11, ROW_HIDDEN, 0, COL_DY11, 1);          // Dense_11
     float* small_slabs = reinterpret_cast<float*>((char*)md.scratch + ls_dump_bytes(md.m));
-    rc = launch_nerf_wgrad(w, first, md.save, md.scratch, n_tiles, md.grads, st, WgLayout{kSaveTileSlots, kGradTileSlots},
+    // interleaved walk: at any moment the 256 workgroups read neighbouring tiles (one 80 MB window moving through the save
+    // and the dump) instead of 256 places 1/256 of the buffers apart — measured 0.60 vs 0.68 ms for the finish phase
+    rc = launch_nerf_wgrad(w, first, md.save, md.scratch, n_tiles, md.grads, st, WgLayout{kSaveTileSlots, kGradTileSlots, 1},
                            small_slabs, false, false);
     if (rc) return rc;
     fold.w[k] = w;

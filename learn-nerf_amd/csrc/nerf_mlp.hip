@@ -715,8 +715,8 @@ int lnrf::launch_nerf_wgrad(const WgradArgs& args, int blocks, const void* xbuf,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(max dynamic LDS)");
   {
-    static const int il = exp_env_int("LNRF_WGRAD_INTERLEAVE", 0);  // experiment builds only (common.h)
-    lay.interleave = il;
+    static const int il = exp_env_int("LNRF_WGRAD_INTERLEAVE", -1);  // experiment builds only (common.h): overrides the caller
+    if (il >= 0) lay.interleave = il;
   }
   if (plain)
     hipLaunchKernelGGL(nerf_wgrad_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args,

@@ -273,3 +273,23 @@ def test_layer_stationary_backward_equals_two_launch_backward(m):
             assert rel < 1e-5, (f"Dense_{i}.{name}", rel)
             off += n
     assert torch.equal(grads["ls"], grads["ls_again"])
+
+
+def test_forward_for_the_layer_stationary_backward():
+    """lnrf_nerf_mlp_fwd_ls (the saving forward without the hidden layers' ReLU-mask slots) must return bit-identical
+    density / rgb to lnrf_nerf_mlp_fwd, and a save it wrote must be refused by the chain backward (which reads those
+    slots) instead of producing wrong gradients."""
+    model, params, flat = make_model("bf16")
+    m = 4096 + 5
+    x, d, gen = make_points(m, seed=5)
+    outs = {}
+    for kind in ("split", "ls"):
+        model.backward_kernel = kind
+        dens, rgb, _, ctx = model.forward_points(flat, x.cuda(), d.cuda(), save=True)
+        outs[kind] = (dens.clone(), rgb.clone(), ctx)
+    assert torch.equal(outs["ls"][0], outs["split"][0]) and torch.equal(outs["ls"][1], outs["split"][1])
+    assert outs["ls"][2]["hidden_masks"] is False and outs["split"][2]["hidden_masks"] is True
+    model.backward_kernel = "split"
+    g = torch.zeros_like(flat)
+    with pytest.raises(ValueError, match="layer-stationary"):
+        model.backward(outs["ls"][2], torch.zeros(m, device="cuda"), torch.zeros(m, 3, device="cuda"), None, g)
