@@ -261,6 +261,12 @@ __global__ __launch_bounds__(kLsThreads) void nerf_bwd_ls_kernel(LsArgs args) {
     const char* ybuf = xbuf + 16 * kFragBytes;
 
     LS_STAMP(0);
+#ifdef LS_STRESS  // hand-off test under uneven load (tools/ls_variants.sh): some stages stall for several tile times now and then
+    if ((stage == 2 || stage == 5) && (i % 11) == stage) {
+      for (int z = 0; z < (stage == 2 ? 4 : 9); ++z) __builtin_amdgcn_s_sleep(127);
+    }
+    if (stage == 6 && (i & 1)) __builtin_amdgcn_s_sleep(40);
+#endif
     {
       const int want = i + kLsDist < n_my ? i + kLsDist + 1 : n_my;
       if (ready < want) wait_ready(want);  // uniform: `ready` comes from LDS words every wave reads after a barrier
