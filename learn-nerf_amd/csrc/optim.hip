@@ -129,7 +129,7 @@ extern "C" int lnrf_adam_step_norms(float* p, const float* g, float* m, float* v
   const double bc2 = 1.0 - pow((double)b2, (double)step);
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 256) blocks = 256;  // every workgroup ends with two atomics on the same two words (~12 ns each, serialised)
   hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v,
                      n, lr, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / bc2), grad_scale, sq_norms);
   LNRF_LAUNCH_CHECK();
