@@ -631,7 +631,9 @@ extern "C" int lnrf_composite_fwd(const float* rays, int64_t ray_stride, const f
   LNRF_CHECK_ARG(n_aux >= 0 && n_aux <= kMaxAux && (n_aux == 0 || aux), "bad aux");
   LNRF_CHECK_ARG(!coords || rays, "coords needs rays");
   if (n_rays == 0) return LNRF_OK;
-  const int wpb = 4;
+  // with a squared-error sum every workgroup ends in one atomic on the same word (~12 ns each, serialised): 16 rays per
+  // workgroup instead of 4 then (256 instead of 1,024 atomics at 4,096 rays)
+  const int wpb = (sq_err && targets) ? 16 : 4;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((n_rays + wpb - 1) / wpb)),
                      dim3(wpb * 64), 0, as_stream(stream), rays, ray_stride, ts, t_min, t_max, mask,
                      density, rgb, aux, n_aux, background, n_rays, t, outputs, alphas, coords,
