@@ -516,11 +516,13 @@ constexpr int kBwdHeadStages = bwd_base(2) / kStageFrags;  // 6
 __global__ __launch_bounds__(kThreads) void nerf_bwd_head_kernel(
     const char* __restrict__ packed, const char* __restrict__ save, const float* __restrict__ density,
     const float* __restrict__ rgb, const float* __restrict__ g_density, const float* __restrict__ g_rgb,
-    int64_t M, int64_t n_tiles, char* __restrict__ gdump) {
+    int64_t M, int64_t n_tiles, char* __restrict__ gdump, unsigned* __restrict__ zero_words, int n_zero_words) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * kWaves + wave;
+  // the pipeline launch behind this one starts from zero hand-off counters: cleared here instead of by a memset launch
+  for (int i = blockIdx.x * kThreads + tid; i < n_zero_words; i += gridDim.x * kThreads) zero_words[i] = 0u;
   Ring<kBwdHeadStages, BwdHeadSeq> ring;
   ring.stream = packed + kPackBwdOff;
   ring.wave = wave;
@@ -663,10 +665,11 @@ static int ls_backward(const LsModel* mdl, int n_models, int phases, hipStream_t
     if (phases & 1) {
       hipLaunchKernelGGL(nerf_bwd_head_kernel, dim3((unsigned)(n_tiles / kWaves)), dim3(kThreads),
                          kRingBytes + round_up(kBiasFloats * 4, 1024), st, (const char*)md.packed, (const char*)md.save,
-                         md.density, md.rgb, md.g_density, md.g_rgb, md.m, n_tiles, sc);
+                         md.density, md.rgb, md.g_density, md.g_rgb, md.m, n_tiles, sc, counters,
+                         (phases & 2) ? (int)(ls_counter_bytes() / sizeof(unsigned)) : 0);
       LNRF_LAUNCH_CHECK();
     }
-    if (phases & 2) {
+    if ((phases & 3) == 2) {  // pipeline phase on its own (bench sections): nobody cleared the counters yet
       hipError_t e = hipMemsetAsync(counters, 0, ls_counter_bytes(), st);
       if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
     }
