@@ -58,6 +58,15 @@ int lnrf_host_nrm_weight_index(int g, int lane, int j) {
   return nrm_weight_index(u, loc / nrm_nk(u), loc % nrm_nk(u), lane, j);
 }
 int lnrf_host_xemb_feat(int ks, int h, int j) { return xemb_feat(ks, h, j); }
+// slot orders of the save / gradient-dump tiles: what 0 x_emb, 1 h_l (arg = l), 2 z, 3 d_emb, 4 h10, 5 masks, 6 slots per tile
+int lnrf_host_save_slot(int what, int arg) {
+  return what == 0 ? kSaveXin : what == 1 ? kSaveH + 16 * arg : what == 2 ? kSaveZ : what == 3 ? kSaveDin
+       : what == 4 ? kSaveH10 : what == 5 ? kSaveMask : kSaveSlots;
+}
+// what 0 dy11, 1 dy10m, 2 dy_l (arg = l), 3 slots per tile
+int lnrf_host_grad_slot(int what, int arg) {
+  return what == 0 ? kGradDy11 : what == 1 ? kGradDy10m : what == 2 ? grad_dy_slot(arg) : kGradSlots;
+}
 int lnrf_host_demb_feat(int ks, int h, int j) { return demb_feat(ks, h, j); }
 int lnrf_host_dump_lane_off(int slot, int c, int hh) { return dump_lane_off(slot, c, hh); }
 void lnrf_host_sincos_pe(float r, float* s, float* c) { lnrf::sincos_pe(r, s, c); }

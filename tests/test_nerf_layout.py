@@ -211,3 +211,18 @@ def test_emulated_forward_chain_matches_oracle(H):
     rd, rr, _ = OM.nerf_mlp(flat.double(), x.double(), d.double(), operand_round=OM.bf16_round)
     assert np.abs(rgb - rr.numpy()).max() < 2e-5
     assert np.abs(density - rd.numpy()[:, 0]).max() < 2e-5
+
+
+def test_slot_orders_keep_the_merged_weight_gradient_operands_adjacent(H):
+    """nerf_layout.h: the weight-gradient problems [z | d_emb] x dy10m and x_emb x [dy0 | dy5] read ONE run of slots per
+    operand, and the head-with-weights experiment one run of 26 (z, d_emb, h10): the slot orders must keep those
+    neighbours, every tensor on an even slot (fragment pairs / the parity swizzle of dump_lane_off), nothing overlapping."""
+    S, G = H.lnrf_host_save_slot, H.lnrf_host_grad_slot
+    assert S(3, 0) == S(2, 0) + 16 and S(4, 0) == S(3, 0) + 2          # z, d_emb, h10
+    assert S(1, 0) == S(0, 0) + 4 and S(2, 0) == S(1, 7) + 16           # x_emb, h0..h7, z
+    assert S(5, 0) == S(4, 0) + 8 and S(6, 0) == S(5, 0) + 9 == 167
+    assert all(S(w, a) % 2 == 0 for w, a in [(0, 0), (2, 0), (3, 0), (4, 0)] + [(1, l) for l in range(8)])
+    dy = [G(2, l) for l in range(9)]
+    assert G(2, 5) == G(2, 0) + 16                                       # dy5 right behind dy0
+    assert sorted(dy) == list(range(G(1, 0) + 10, G(3, 0), 16)) and all(v % 2 == 0 for v in dy)
+    assert G(0, 0) == 0 and G(1, 0) == 2 and G(3, 0) == 156
